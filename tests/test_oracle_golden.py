@@ -1,0 +1,174 @@
+"""Pin the oracle (oracle/sketchedit_oracle.py) against vectors captured from the reference
+itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sketchedit_oracle as O
+from sketchedit_amd import synth
+
+TOL = 2e-6
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _weights(gain):
+    return synth.make_state_dict("M", 0, gain), synth.make_state_dict("G", 0, gain)
+
+
+def _maxdiff(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def _summary(a):
+    a = np.asarray(a, np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.min(), a.max()])
+
+
+@pytest.fixture(scope="module")
+def e2e64(golden_dir):
+    g = _load(golden_dir, "e2e_64.npz")
+    gain, wseed, iseed, B, H, W = g["meta"]
+    WM, WG = _weights(float(gain))
+    img, sk = synth.make_inputs(int(B), int(H), int(W), seed=int(iseed))
+    taps = {}
+    with torch.no_grad():
+        mask, mask_image = O.netM_forward(WM, img, sk)
+        hard = (mask > 0.5).float()
+        coarse, fine = O.netG_forward(WG, img, img, hard, hard, sk, taps=taps)
+    return g, dict(mask=mask, mask_image=mask_image, hard=hard, coarse=coarse, fine=fine, taps=taps,
+                   img=torch.from_numpy(img))
+
+
+def test_netM_64(e2e64):
+    g, r = e2e64
+    assert _maxdiff(r["mask"], g["mask"]) < TOL
+    assert _maxdiff(r["mask_image"], g["mask_image"]) < TOL
+    assert np.array_equal(r["hard"].numpy(), g["hard_mask"])
+    assert 0.1 < g["hard_mask"].mean() < 0.9
+
+
+def test_netG_64(e2e64):
+    g, r = e2e64
+    assert _maxdiff(r["coarse"], g["coarse"]) < TOL
+    assert _maxdiff(r["fine"], g["fine"]) < TOL
+    assert _maxdiff(r["taps"]["style_vec"], g["style_vec"]) < TOL
+    assert _maxdiff(r["taps"]["similar"], g["similar"]) < TOL
+    assert _maxdiff(r["taps"]["attn_out"], g["attn_out"]) < 2e-5
+    np.testing.assert_allclose(_summary(r["taps"]["coarse_enc"]), g["coarse_enc_sum"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(_summary(r["taps"]["pmconv6"]), g["pmconv6_sum"], rtol=1e-5, atol=1e-5)
+
+
+def test_composed_64(e2e64):
+    g, r = e2e64
+    composed = r["fine"] * r["mask"] + r["img"] * (1 - r["mask"])
+    assert _maxdiff(composed, g["composed"]) < TOL
+
+
+def test_inference_entry_64(golden_dir):
+    g = _load(golden_dir, "e2e_64.npz")
+    gain, wseed, iseed, B, H, W = g["meta"]
+    WM, WG = _weights(float(gain))
+    img, sk = synth.make_inputs(int(B), int(H), int(W), seed=int(iseed))
+    out = O.inference(WM, WG, img, sk)
+    assert _maxdiff(out["composed"], g["composed"]) < TOL
+    assert _maxdiff(out["mask"], g["mask"]) < TOL
+
+
+def test_nonsquare_40x72(golden_dir):
+    g = _load(golden_dir, "e2e_40x72.npz")
+    gain, wseed, iseed, B, H, W = g["meta"]
+    WM, WG = _weights(float(gain))
+    img, sk = synth.make_inputs(int(B), int(H), int(W), seed=int(iseed))
+    out = O.inference(WM, WG, img, sk)
+    for k in ("composed", "mask", "coarse", "fine"):
+        assert _maxdiff(out[k], g[k]) < TOL, k
+    assert np.array_equal(out["hard_mask"].numpy(), g["hard_mask"])
+
+
+@pytest.mark.parametrize("tag,flags", [
+    ("avg", dict(pool_type="avg")), ("nocam", dict(use_cam=False)), ("nomaskcc", dict(no_mask_cc=True)),
+    ("nomaskcoarse", dict(no_mask_coarse=True)), ("nojoint", dict(joint_train_inp=False))])
+def test_flag_variants_64(golden_dir, tag, flags):
+    g = _load(golden_dir, "variants_64.npz")
+    e = _load(golden_dir, "e2e_64.npz")
+    WM, WG = _weights(float(e["meta"][0]))
+    img, sk = synth.make_inputs(1, 64, 64, seed=1234)
+    out = O.inference(WM, WG, img, sk, **flags)
+    assert _maxdiff(out["coarse"], g[tag + ".coarse"]) < TOL
+    assert _maxdiff(out["fine"], g[tag + ".fine"]) < TOL
+
+
+def test_e2e_256(golden_dir):
+    g = _load(golden_dir, "e2e_256.npz")
+    gain, wseed, iseed, B, H, W = g["meta"]
+    WM, WG = _weights(float(gain))
+    img, sk = synth.make_inputs(int(B), int(H), int(W), seed=int(iseed))
+    out = O.inference(WM, WG, img, sk)
+    hard = out["hard_mask"].numpy()
+    assert np.array_equal(np.packbits(hard.astype(np.uint8)), g["hard_mask_bits"])
+    for k in ("composed", "mask", "coarse", "fine"):
+        crop = out[k][:, :, 96:160, 96:160]
+        assert _maxdiff(crop, g[k + "_crop"]) < 5e-6, k
+        np.testing.assert_allclose(_summary(out[k]), g[k + "_sum"], rtol=2e-5, atol=2e-4)
+
+
+OPS = [("c3_s1_d1_elu", 8, 16, 3, 1, 1, "elu", 12, 16), ("c3_s2_d1_elu", 8, 16, 3, 2, 1, "elu", 12, 16),
+       ("c3_s1_d2_elu", 8, 16, 3, 1, 2, "elu", 12, 16), ("c3_s1_d16_elu", 8, 16, 3, 1, 16, "elu", 20, 24),
+       ("c3_s1_d1_relu", 8, 16, 3, 1, 1, "relu", 12, 16), ("c3_s1_d1_none", 12, 1, 3, 1, 1, None, 12, 16),
+       ("c3_s1_d1_rgb", 12, 3, 3, 1, 1, "elu", 12, 16), ("c5_s1_d1_elu", 5, 16, 5, 1, 1, "elu", 12, 16)]
+
+
+@pytest.mark.parametrize("case", OPS, ids=[c[0] for c in OPS])
+def test_op_gated_conv(golden_dir, case):
+    name, cin, cout, k, s, r, act, H, W = case
+    g = _load(golden_dir, "ops.npz")
+    w = torch.from_numpy(synth.uniform(7, name + ".w", (cout, cin, k, k), -0.5, 0.5))
+    b = torch.from_numpy(synth.uniform(7, name + ".b", (cout,), -0.5, 0.5))
+    x = torch.from_numpy(synth.uniform(7, name + ".x", (2, cin, H, W), -1, 1))
+    y = O.gated_conv(x, w, b, s, r, act)
+    assert y.shape == g["op." + name].shape
+    assert _maxdiff(y, g["op." + name]) < TOL
+
+
+def test_op_deconv(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    w = torch.from_numpy(synth.uniform(7, "deconv.w", (16, 8, 3, 3), -0.5, 0.5))
+    b = torch.from_numpy(synth.uniform(7, "deconv.b", (16,), -0.5, 0.5))
+    x = torch.from_numpy(synth.uniform(7, "deconv.x", (2, 8, 6, 8), -1, 1))
+    assert _maxdiff(O.gated_deconv(x, w, b), g["op.deconv"]) < TOL
+
+
+def att_inputs():
+    x = torch.from_numpy(synth.uniform(7, "att.x", (2, 8, 12, 16), -1, 1))
+    full = (torch.from_numpy(synth.uniform(7, "att.m", (2, 1, 48, 64), 0, 1)) < 0.6).float()
+    full[1, :, :24] = 1.0
+    full[0, :, 0:16, 0:16] = 1.0
+    full[0, :, 0:14, 3:16] = 1.0
+    return x, full
+
+
+def test_op_attention(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    x, full = att_inputs()
+    out, P = O.contextual_attention(x, full)
+    assert _maxdiff(P, g["op.att.similar"]) < TOL
+    assert _maxdiff(out, g["op.att.out"]) < 1e-5
+    # some keys are invalid in this case (the multiplicative-zero path is exercised)
+    ms = torch.nn.functional.avg_pool2d(full, 4, 4)
+    valid = torch.nn.functional.unfold(1 - ms, 4, stride=2).mean(1)
+    assert (valid <= 0.1).any() and (valid > 0.1).any()
+
+
+def test_op_attention_all_invalid(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    x, _ = att_inputs()
+    ones = torch.ones(2, 1, 48, 64)
+    out, P = O.contextual_attention(x, ones)
+    assert _maxdiff(P, g["op.att_allinvalid.similar"]) < TOL
+    assert _maxdiff(out, g["op.att_allinvalid.out"]) < 1e-5
+    assert abs(float(P[0, 0, 0, 0]) - 1.0 / P.shape[1]) < 1e-7
