@@ -1,0 +1,91 @@
+/* libsketchedit_hip.so -- C-ABI of the MI355X (gfx950) SketchEdit inference path.
+ *
+ * The reference (zengxianyu/sketchedit) has no FFI: its de-facto boundary is Python,
+ *   models.create_model(opt)(data, mode='inference')     models/editline2_model.py:107-133
+ *   netM(x, guide) -> (mask, mask_image)                 models/networks/editline2_g.py:59-94
+ *   netG(x, x2, mask, mask2, guide) -> (coarse, fine)    models/networks/editline_g.py:119-221
+ * and below it torch.nn.functional.  This header is what a ctypes binding on the reference side
+ * binds instead of that arithmetic; sketchedit_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *  - every tensor pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr()),
+ *    fp32, contiguous NCHW exactly as the reference's tensors; weights are HOST pointers.
+ *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls only enqueue work,
+ *    there is no hidden device synchronisation and no allocation inside a forward: the caller
+ *    passes a workspace of at least se_workspace_bytes(ctx, B, H, W) bytes.
+ *  - return value 0 = ok, non-zero = error (se_last_error(ctx) describes it); no C++ exception
+ *    crosses the boundary.  A context serialises its own forwards with an internal mutex, so one
+ *    ctx may be shared by threads (demo.py:120 runs Flask threaded) -- one ctx per stream is faster.
+ *  - H and W must be multiples of 8 (demo.py:43-45 enforces the same for the reference).
+ */
+#ifndef SKETCHEDIT_HIP_H
+#define SKETCHEDIT_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct se_ctx se_ctx;
+
+enum { SE_NET_G = 0, SE_NET_M = 1 };
+
+/* netG option flags: models/networks/editline_g.py:15-23, options/base_options.py:19 */
+enum {
+  SE_FLAG_USE_CAM = 1,         /* --use_cam */
+  SE_FLAG_POOL_MAX = 2,        /* --pool_type max (unset: avg) */
+  SE_FLAG_NO_MASK_CC = 4,      /* --no_mask_cc */
+  SE_FLAG_NO_MASK_COARSE = 8,  /* --no_mask_coarse */
+  SE_FLAG_JOINT_TRAIN_INP = 16 /* --joint_train_inp */
+};
+
+/* replaces networks.create_network's .cuda() (models/networks/__init__.py:30-38) */
+int se_create(int device_id, se_ctx** out);
+void se_destroy(se_ctx* ctx);
+const char* se_last_error(se_ctx* ctx);
+const char* se_version(void);
+
+/* replaces util.load_network / load_state_dict (util/util.py:214-225).  `name` is a state_dict key
+ * ("conv1.weight", "conv1.bias", a leading "module." is stripped); `host` points at shape[0..ndim)
+ * fp32 values in the checkpoint's own layout (weight OIHW, bias O).  Unknown keys or wrong shapes
+ * are errors (strict load).  se_weights_ready() reports 1 when every tensor of both nets is set. */
+int se_load_weights(se_ctx* ctx, int net_id, const char* name, const float* host, const int* shape, int ndim);
+int se_weights_ready(se_ctx* ctx);
+
+size_t se_workspace_bytes(se_ctx* ctx, int B, int H, int W);
+
+/* MDGenerator.forward (editline2_g.py:59-94).  image (B,3,H,W), sketch (B,1,H,W) ->
+ * mask_out (B,1,H,W); maskim_out (B,3,H,W) may be NULL (its decoder is then skipped, as in
+ * mode='inference' where the value is unused). */
+int se_netM_forward(se_ctx* ctx, void* stream, const float* image, const float* sketch, float* mask_out,
+                    float* maskim_out, void* workspace, size_t workspace_bytes, int B, int H, int W);
+
+/* DeepFillC2Generator.forward (editline_g.py:119-221).  x,x2 (B,3,H,W); mask,mask2,guide (B,1,H,W);
+ * coarse_out / fine_out (B,3,H,W), coarse_out may be NULL. */
+int se_netG_forward(se_ctx* ctx, void* stream, const float* x, const float* x2, const float* mask,
+                    const float* mask2, const float* guide, float* coarse_out, float* fine_out, void* workspace,
+                    size_t workspace_bytes, int B, int H, int W, int flags);
+
+/* EditLine2Model.forward(mode='inference') (editline2_model.py:128-133 + generate_fake :338-370):
+ * netM -> (mask > 0.5) -> netG -> composed = fine*mask + image*(1-mask) with the SOFT mask.
+ * Optional outputs (may be NULL): hard_out (B,1,H,W), maskim_out, coarse_out, fine_out (B,3,H,W)
+ * -- the extra tensors of mode='visualize' (:134-145). */
+int se_inference(se_ctx* ctx, void* stream, const float* image, const float* sketch, float* composed_out,
+                 float* mask_out, float* hard_out, float* maskim_out, float* coarse_out, float* fine_out,
+                 void* workspace, size_t workspace_bytes, int B, int H, int W, int flags);
+
+/* ---- per-op entry points (unit tests; same kernels as the forwards) ----------------------------
+ * gen_conv / gen_deconv (models/networks/utils.py:9-51): x (B,Cin,H,W) device, w (Cout,Cin,k,k) and
+ * b (Cout) HOST, y device (B, Cout/2 or Cout, Ho, Wo).  act: 0 ELU, 1 ReLU, 2 None (raw conv).
+ * Supported: gated Cout%8==0 (any Cin, k in {3,5}); raw only for k=3, Cin=12, Cout in {1,3}. */
+int se_gated_conv2d(se_ctx* ctx, void* stream, const float* x, const float* w_host, const float* b_host, float* y,
+                    int B, int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample);
+/* cam_1 + cam_2 (models/networks/splitcam.py:57-108,147-174 as configured at editline_g.py:35-42,
+ * 203-207): x (B,96,h,w), mask_full (B,1,4h,4w) -> out (B,96,h,w); similar_out (B,L,hs,ws) may be NULL. */
+int se_attention(se_ctx* ctx, void* stream, const float* x, const float* mask_full, float* out, float* similar_out,
+                 int B, int h, int w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,260 @@
+"""ctypes binding of libsketchedit_hip.so (C-ABI in include/sketchedit_hip.h).
+
+This is the thin layer a maintainer of the reference would add: torch owns the
+device tensors, this module passes their raw pointers + the current HIP stream to the library.
+There is NO fallback: if the library is missing or fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsketchedit_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["se_kernels.hip", "se_api.hip"]
+
+SE_NET_G, SE_NET_M = 0, 1
+FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
+
+# every symbol declared in include/sketchedit_hip.h
+SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
+           "se_workspace_bytes", "se_netM_forward", "se_netG_forward", "se_inference", "se_gated_conv2d",
+           "se_attention"]
+
+
+class SketchEditHipError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> sketchedit_amd/lib/libsketchedit_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "se_kernels.h"), os.path.join(_HERE, "..", "include", "sketchedit_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SketchEditHipError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU or PyTorch fallback for this path)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        c_f = ctypes.c_void_p  # device/host float pointers are passed as raw addresses
+        vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        lib.se_create.argtypes = [ci, ctypes.POINTER(vp)]
+        lib.se_create.restype = ci
+        lib.se_destroy.argtypes = [vp]
+        lib.se_destroy.restype = None
+        lib.se_last_error.argtypes = [vp]
+        lib.se_last_error.restype = ctypes.c_char_p
+        lib.se_version.argtypes = []
+        lib.se_version.restype = ctypes.c_char_p
+        lib.se_load_weights.argtypes = [vp, ci, ctypes.c_char_p, c_f, ctypes.POINTER(ci), ci]
+        lib.se_load_weights.restype = ci
+        lib.se_weights_ready.argtypes = [vp]
+        lib.se_weights_ready.restype = ci
+        lib.se_workspace_bytes.argtypes = [vp, ci, ci, ci]
+        lib.se_workspace_bytes.restype = sz
+        lib.se_netM_forward.argtypes = [vp, vp, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci]
+        lib.se_netM_forward.restype = ci
+        lib.se_netG_forward.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
+        lib.se_netG_forward.restype = ci
+        lib.se_inference.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
+        lib.se_inference.restype = ci
+        lib.se_gated_conv2d.argtypes = [vp, vp, c_f, c_f, c_f, c_f] + [ci] * 10
+        lib.se_gated_conv2d.restype = ci
+        lib.se_attention.argtypes = [vp, vp, c_f, c_f, c_f, c_f, ci, ci, ci]
+        lib.se_attention.restype = ci
+        _lib = lib
+        return lib
+
+
+def flags_from_opt(opt):
+    """netG flag word from a reference-style options namespace (editline_g.py:15-23, base_options.py:19)."""
+    f = 0
+    if getattr(opt, "use_cam", False):
+        f |= FLAG_USE_CAM
+    pool = getattr(opt, "pool_type", "avg")
+    if pool == "max":
+        f |= FLAG_POOL_MAX
+    elif pool != "avg":
+        raise NotImplementedError(pool)        # editline_g.py:164-165
+    if getattr(opt, "no_mask_cc", False):
+        f |= FLAG_NO_MASK_CC
+    if getattr(opt, "no_mask_coarse", False):
+        f |= FLAG_NO_MASK_COARSE
+    if getattr(opt, "joint_train_inp", False):
+        f |= FLAG_JOINT_TRAIN_INP
+    return f
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _check_dev(*ts):
+    import torch
+    for t in ts:
+        if t is None:
+            continue
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise SketchEditHipError("expected contiguous float32 CUDA(HIP) tensors")
+
+
+class Engine:
+    """One se_ctx on one GPU + its workspace.  Thread-safe (the library serialises forwards per ctx)."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise SketchEditHipError("no HIP device visible: the sketchedit_amd forward only runs on an MI355X")
+        self.lib = load_library()
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        if self.lib.se_create(self.device, ctypes.byref(h)) != 0:
+            raise SketchEditHipError("se_create: " + self.lib.se_last_error(None).decode())
+        self.h = h
+        self._ws = None
+        self._ws_lock = threading.Lock()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.se_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, what):
+        raise SketchEditHipError("%s: %s" % (what, self.lib.se_last_error(self.h).decode()))
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, net, state_dict):
+        """net in {'G','M'}; state_dict: key -> array/tensor in checkpoint layout (strict)."""
+        net_id = SE_NET_G if net == "G" else SE_NET_M
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (ctypes.c_int * a.ndim)(*a.shape)
+            if self.lib.se_load_weights(self.h, net_id, k.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim):
+                self._err("se_load_weights(%s)" % k)
+
+    def weights_ready(self):
+        return bool(self.lib.se_weights_ready(self.h))
+
+    # ---- workspace -----------------------------------------------------------------------------
+    def workspace(self, B, H, W):
+        import torch
+        need = self.lib.se_workspace_bytes(self.h, B, H, W)
+        if need == 0:
+            self._err("se_workspace_bytes")
+        with self._ws_lock:
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device="cuda:%d" % self.device)
+            return self._ws
+
+    def _stream(self):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- forwards ------------------------------------------------------------------------------
+    def netM(self, image, sketch, want_image=True):
+        import torch
+        _check_dev(image, sketch)
+        B, _, H, W = image.shape
+        ws = self.workspace(B, H, W)
+        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=image.device)
+        mim = torch.empty((B, 3, H, W), dtype=torch.float32, device=image.device) if want_image else None
+        if self.lib.se_netM_forward(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(mask), _ptr(mim),
+                                    _ptr(ws), ws.numel(), B, H, W):
+            self._err("se_netM_forward")
+        return mask, mim
+
+    def netG(self, x, x2, mask, mask2, guide, flags):
+        import torch
+        _check_dev(x, x2, mask, mask2, guide)
+        B, _, H, W = x.shape
+        ws = self.workspace(B, H, W)
+        coarse = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+        fine = torch.empty_like(coarse)
+        if self.lib.se_netG_forward(self.h, self._stream(), _ptr(x), _ptr(x2), _ptr(mask), _ptr(mask2), _ptr(guide),
+                                    _ptr(coarse), _ptr(fine), _ptr(ws), ws.numel(), B, H, W, flags):
+            self._err("se_netG_forward")
+        return coarse, fine
+
+    def inference(self, image, sketch, flags, visualize=False, out=None):
+        """-> dict(composed, mask[, hard, maskim, coarse, fine]).  `out` may hold preallocated composed/mask."""
+        import torch
+        _check_dev(image, sketch)
+        B, _, H, W = image.shape
+        ws = self.workspace(B, H, W)
+        dev = image.device
+        composed = out["composed"] if out else torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        mask = out["mask"] if out else torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        r = dict(composed=composed, mask=mask)
+        hard = maskim = coarse = fine = None
+        if visualize:
+            hard = torch.empty_like(mask)
+            maskim, coarse, fine = (torch.empty_like(composed) for _ in range(3))
+            r.update(hard=hard, maskim=maskim, coarse=coarse, fine=fine)
+        if self.lib.se_inference(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(composed), _ptr(mask),
+                                 _ptr(hard), _ptr(maskim), _ptr(coarse), _ptr(fine), _ptr(ws), ws.numel(), B, H, W,
+                                 flags):
+            self._err("se_inference")
+        return r
+
+    # ---- per-op entry points (unit tests) --------------------------------------------------------
+    def gated_conv2d(self, x, w, b, stride=1, rate=1, act="elu", upsample=False):
+        import torch
+        _check_dev(x)
+        w = np.ascontiguousarray(w, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        B, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        pad = int(rate * (k - 1) / 2)
+        if upsample:
+            Ho, Wo = 2 * H, 2 * W
+        else:
+            Ho = (H + 2 * pad - rate * (k - 1) - 1) // stride + 1
+            Wo = (W + 2 * pad - rate * (k - 1) - 1) // stride + 1
+        raw = act is None or Cout == 3
+        y = torch.empty((B, Cout if raw else Cout // 2, Ho, Wo), dtype=torch.float32, device=x.device)
+        acode = {"elu": 0, "relu": 1, None: 2}[act]
+        if self.lib.se_gated_conv2d(self.h, self._stream(), _ptr(x), w.ctypes.data_as(ctypes.c_void_p),
+                                    b.ctypes.data_as(ctypes.c_void_p), _ptr(y), B, Cin, H, W, Cout, k, stride, rate,
+                                    acode, int(upsample)):
+            self._err("se_gated_conv2d")
+        return y
+
+    def attention(self, x, mask_full, want_similar=False):
+        import torch
+        _check_dev(x, mask_full)
+        B, C, h, w = x.shape
+        assert C == 96
+        hs, ws = (h - 4) // 2 + 1, (w - 4) // 2 + 1
+        out = torch.empty_like(x)
+        sim = torch.empty((B, hs * ws, hs, ws), dtype=torch.float32, device=x.device) if want_similar else None
+        if self.lib.se_attention(self.h, self._stream(), _ptr(x), _ptr(mask_full), _ptr(out), _ptr(sim), B, h, w):
+            self._err("se_attention")
+        return (out, sim) if want_similar else out

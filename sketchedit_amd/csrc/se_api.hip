@@ -1,0 +1,680 @@
+// Host side of libsketchedit_hip.so: context, weight repacking, workspace arena and the forward
+// plans of netM / netG / inference behind the C-ABI declared in include/sketchedit_hip.h.
+//
+// Layer tables restate the reference constructors
+//   DeepFillC2Generator.__init__  /root/reference/models/networks/editline_g.py:44-100
+//   MDGenerator.__init__          /root/reference/models/networks/editline2_g.py:18-43
+// and the plans restate the forward methods (editline_g.py:119-221, editline2_g.py:59-94,
+// editline2_model.py:128-133,338-370).
+#include "../../include/sketchedit_hip.h"
+#include "se_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace se;
+
+namespace {
+
+enum { ACT_ELU = 0, ACT_RELU = 1, ACT_NONE = 2 };
+
+struct LayerDef {
+  const char* name;
+  int cin, cout, k, stride, rate, act, up;
+};
+
+#define ENC(p)                                                                                    \
+  {p "2_downsample", 24, 96, 3, 2, 1, ACT_ELU, 0}, {p "3", 48, 96, 3, 1, 1, ACT_ELU, 0},          \
+      {p "4_downsample", 48, 192, 3, 2, 1, ACT_ELU, 0}, {p "5", 96, 192, 3, 1, 1, ACT_ELU, 0},    \
+      {p "6", 96, 192, 3, 1, 1, ACT_ELU, 0}, {p "7_atrous", 96, 192, 3, 1, 2, ACT_ELU, 0},        \
+      {p "8_atrous", 96, 192, 3, 1, 4, ACT_ELU, 0}, {p "9_atrous", 96, 192, 3, 1, 8, ACT_ELU, 0}, \
+      {p "10_atrous", 96, 192, 3, 1, 16, ACT_ELU, 0}
+#define DEC(p, c11in, c17out)                                                                        \
+  {p "11", c11in, 192, 3, 1, 1, ACT_ELU, 0}, {p "12", 96, 192, 3, 1, 1, ACT_ELU, 0},                 \
+      {p "13_upsample_conv", 96, 96, 3, 1, 1, ACT_ELU, 1}, {p "14", 48, 96, 3, 1, 1, ACT_ELU, 0},    \
+      {p "15_upsample_conv", 48, 48, 3, 1, 1, ACT_ELU, 1}, {p "16", 24, 24, 3, 1, 1, ACT_ELU, 0},    \
+      {p "17", 12, c17out, 3, 1, 1, ACT_NONE, 0}
+
+const LayerDef G_LAYERS[] = {
+    {"conv1", 5, 48, 5, 1, 1, ACT_ELU, 0}, ENC("conv"), DEC("conv", 192, 3),
+    {"wconv1", 5, 48, 5, 1, 1, ACT_ELU, 0}, ENC("wconv"),
+    {"xconv1", 3, 48, 5, 1, 1, ACT_ELU, 0},
+    {"xconv2_downsample", 24, 48, 3, 2, 1, ACT_ELU, 0}, {"xconv3", 24, 96, 3, 1, 1, ACT_ELU, 0},
+    {"xconv4_downsample", 48, 96, 3, 2, 1, ACT_ELU, 0}, {"xconv5", 48, 192, 3, 1, 1, ACT_ELU, 0},
+    {"xconv6", 96, 192, 3, 1, 1, ACT_ELU, 0}, {"xconv7_atrous", 96, 192, 3, 1, 2, ACT_ELU, 0},
+    {"xconv8_atrous", 96, 192, 3, 1, 4, ACT_ELU, 0}, {"xconv9_atrous", 96, 192, 3, 1, 8, ACT_ELU, 0},
+    {"xconv10_atrous", 96, 192, 3, 1, 16, ACT_ELU, 0},
+    {"pmconv1", 3, 48, 5, 1, 1, ACT_ELU, 0},
+    {"pmconv2_downsample", 24, 48, 3, 2, 1, ACT_ELU, 0}, {"pmconv3", 24, 96, 3, 1, 1, ACT_ELU, 0},
+    {"pmconv4_downsample", 48, 192, 3, 2, 1, ACT_ELU, 0}, {"pmconv5", 96, 192, 3, 1, 1, ACT_ELU, 0},
+    {"pmconv6", 96, 192, 3, 1, 1, ACT_RELU, 0}, {"pmconv9", 96, 192, 3, 1, 1, ACT_ELU, 0},
+    {"pmconv10", 96, 192, 3, 1, 1, ACT_ELU, 0},
+    DEC("allconv", 192, 3),
+};
+const LayerDef M_LAYERS[] = {
+    {"conv1", 4, 48, 5, 1, 1, ACT_ELU, 0}, ENC("conv"), DEC("conv", 96, 3), DEC("conv_mask_", 96, 1),
+};
+const int NG = sizeof(G_LAYERS) / sizeof(LayerDef), NM = sizeof(M_LAYERS) / sizeof(LayerDef);
+
+struct Layer {
+  LayerDef def;
+  std::vector<float> w, b;    // host copies in checkpoint layout
+  bool have_w = false, have_b = false, packed = false;
+  // packed device image
+  int cfg = -1, NP = 0, nch = 0, G = 0, CGp = 0, T = 0, C0 = 0, C1 = 0;
+  float* d_w = nullptr;
+  float* d_b = nullptr;
+};
+
+// ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
+struct Arena {
+  struct Blk { size_t off, size; bool used; };
+  std::vector<Blk> blks;
+  size_t cap = 0, peak = 0;
+  bool dry = false;
+  char* base = nullptr;
+  void reset(char* b, size_t c, bool d) {
+    base = d ? (char*)4096 : b;   // dry runs only measure: any non-null fake base
+    cap = d ? (size_t)1 << 62 : c; dry = d; peak = 0;
+    blks.clear(); blks.push_back({0, cap, false});
+  }
+  float* alloc(size_t nfloats) {
+    size_t need = (nfloats * 4 + 255) & ~(size_t)255;
+    for (size_t i = 0; i < blks.size(); ++i) {
+      if (!blks[i].used && blks[i].size >= need) {
+        size_t off = blks[i].off;
+        if (blks[i].size > need) {
+          Blk rest{off + need, blks[i].size - need, false};
+          blks[i].size = need;
+          blks.insert(blks.begin() + i + 1, rest);
+        }
+        blks[i].used = true;
+        if (off + need > peak) peak = off + need;
+        return (float*)(base + off);
+      }
+    }
+    return nullptr;
+  }
+  void release(const float* p) {
+    if (!p) return;
+    size_t off = (const char*)p - base;
+    for (size_t i = 0; i < blks.size(); ++i) {
+      if (blks[i].off == off && blks[i].used) {
+        blks[i].used = false;
+        if (i + 1 < blks.size() && !blks[i + 1].used) { blks[i].size += blks[i + 1].size; blks.erase(blks.begin() + i + 1); }
+        if (i > 0 && !blks[i - 1].used) { blks[i - 1].size += blks[i].size; blks.erase(blks.begin() + i); }
+        return;
+      }
+    }
+  }
+};
+
+}  // namespace
+
+struct se_ctx {
+  int device = 0;
+  std::mutex mu;
+  std::string err;
+  std::map<std::string, Layer> G, M;
+  float* zeros = nullptr;   // zero page for out-of-bounds granules
+  Arena arena;
+  hipStream_t st = nullptr;
+  bool dry = false;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(se_ctx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_err = buf;
+  return 1;
+}
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- weight packing -------------------------------------------------------------------------------
+// Build the LDS image [nch][NP][32] of a gated conv: row n = packed output channel, k = flattened
+// (tap, packed input channel); the 16-B slot s of row n is stored at physical slot s ^ ((n>>1)&7).
+// cin_map[pc] = checkpoint input channel of packed channel pc, or -1 for zero padding.
+int choose_cfg(int G) {
+  if (G <= 16) return GC_N24;
+  if (G <= 24) return GC_N48;
+  if (G <= 48) return GC_N96;
+  if (G <= 96) return GC_N192;
+  return -1;
+}
+
+int out_channel_of_row(int cfg, int n, int G, int cout) {
+  // returns checkpoint output channel for packed row n (features [0,G), gates [G,2G)), or -1
+  const int NP = gconv_np(cfg);
+  if (!gconv_mixed(cfg)) {
+    const int NF = NP / 32;  // feature tiles
+    const int nt = n / 16, r = n % 16;
+    if (nt < NF) { int f = nt * 16 + r; return f < G ? f : -1; }
+    int g = (nt - NF) * 16 + r;
+    return g < G ? G + g : -1;
+  }
+  const int nt = n / 16, r = n % 16;
+  if (r < 8) { int f = nt * 8 + r; return f < G ? f : -1; }
+  int g = nt * 8 + (r - 8);
+  return g < G ? G + g : -1;
+}
+
+int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
+  const LayerDef& d = L.def;
+  const int G = d.cout / 2;
+  const int cfg = choose_cfg(G);
+  if (cfg < 0 || (G % 4)) return fail(c, "layer %s: unsupported gated width %d", d.name, G);
+  const int NP = gconv_np(cfg);
+  const int Cp = (int)cin_map.size();          // packed channels per tap (multiple of 4)
+  const int T = d.k * d.k;
+  const int K = T * Cp;
+  const int nch = (K + 31) / 32;
+  std::vector<float> img((size_t)nch * NP * 32, 0.f), bias(NP, 0.f);
+  for (int n = 0; n < NP; ++n) {
+    const int oc = out_channel_of_row(cfg, n, G, d.cout);
+    if (oc < 0) continue;
+    bias[n] = L.b[oc];
+    for (int kf = 0; kf < K; ++kf) {
+      const int tap = kf / Cp, pc = kf % Cp;
+      const int ic = cin_map[pc];
+      if (ic < 0) continue;
+      const int ky = tap / d.k, kx = tap % d.k;
+      const float v = L.w[(((size_t)oc * d.cin + ic) * d.k + ky) * d.k + kx];
+      const int ch = kf / 32, kin = kf % 32, s = kin / 4, e = kin % 4;
+      const int ps = s ^ ((n >> 1) & 7);
+      img[((size_t)ch * NP + n) * 32 + ps * 4 + e] = v;
+    }
+  }
+  if (L.d_w) (void)hipFree(L.d_w);
+  if (L.d_b) (void)hipFree(L.d_b);
+  HIPCHK(c, hipMalloc(&L.d_w, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_b, bias.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_w, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  L.cfg = cfg; L.NP = NP; L.nch = nch; L.G = G; L.CGp = Cp / 4; L.T = T;
+  L.packed = true;
+  return 0;
+}
+
+int pack_small(se_ctx* c, Layer& L) {
+  // raw 3x3 conv 12 -> cout: [cout][9][12]
+  const LayerDef& d = L.def;
+  std::vector<float> img((size_t)d.cout * 9 * 12);
+  for (int oc = 0; oc < d.cout; ++oc)
+    for (int t = 0; t < 9; ++t)
+      for (int ic = 0; ic < 12; ++ic) img[((size_t)oc * 9 + t) * 12 + ic] = L.w[(((size_t)oc * 12 + ic) * 3 + t / 3) * 3 + t % 3];
+  if (L.d_w) (void)hipFree(L.d_w);
+  if (L.d_b) (void)hipFree(L.d_b);
+  HIPCHK(c, hipMalloc(&L.d_w, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_b, d.cout * 4));
+  HIPCHK(c, hipMemcpy(L.d_w, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_b, L.b.data(), d.cout * 4, hipMemcpyHostToDevice));
+  L.packed = true;
+  return 0;
+}
+
+std::vector<int> identity_map(int cin) {
+  const int Cp = (cin + 3) & ~3;
+  std::vector<int> m(Cp, -1);
+  for (int i = 0; i < cin; ++i) m[i] = i;
+  return m;
+}
+
+int pack_net_layer(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  if (d.act == ACT_NONE) return pack_small(c, L);
+  std::vector<int> m;
+  if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
+  else m = identity_map(d.cin);
+  return pack_layer(c, L, m);
+}
+
+// ---- launching one gated conv -----------------------------------------------------------------------
+int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float* src1, int C1, int src1_vec, float* dst,
+              int B, int Hin, int Win, int* Ho_, int* Wo_) {
+  const LayerDef& d = L.def;
+  const int pad = d.rate * (d.k - 1) / 2;                               // utils.py:20
+  int Ho, Wo;
+  if (d.up) { Ho = 2 * Hin; Wo = 2 * Win; }
+  else { Ho = (Hin + 2 * pad - d.rate * (d.k - 1) - 1) / d.stride + 1; Wo = (Win + 2 * pad - d.rate * (d.k - 1) - 1) / d.stride + 1; }
+  if (Ho_) *Ho_ = Ho;
+  if (Wo_) *Wo_ = Wo;
+  if (c->dry) return 0;
+  if (!L.packed) return fail(c, "layer %s: weights not loaded", d.name);
+  if ((C0 + C1) != L.CGp * 4) return fail(c, "layer %s: source channels %d+%d != packed %d", d.name, C0, C1, L.CGp * 4);
+  GConvParams p;
+  memset(&p, 0, sizeof p);
+  p.src0 = src0; p.src1 = src1 ? src1 : src0; p.wpk = L.d_w; p.bias = L.d_b; p.dst = dst; p.zeros = c->zeros;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
+  p.C0 = C0; p.C1 = C1 ? C1 : C0; p.C0g = C0 / 4; p.CG = L.CGp;
+  p.T = L.T; p.KW = d.k; p.stride = d.stride; p.dil = d.rate; p.pad = pad;
+  p.ushift = d.up ? 1 : 0;
+  p.Hlim = d.up ? 2 * Hin : Hin; p.Wlim = d.up ? 2 * Win : Win;
+  p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * Ho * Wo;
+  HIPCHK(c, launch_gconv(L.cfg, p, c->st));
+  return 0;
+}
+
+struct Act {   // an NHWC activation living in the arena
+  float* p = nullptr;
+  int H = 0, W = 0, C = 0;
+};
+
+struct Plan {
+  se_ctx* c;
+  std::map<std::string, Layer>& net;
+  int B;
+  int rc = 0;
+  Plan(se_ctx* c_, std::map<std::string, Layer>& n, int B_) : c(c_), net(n), B(B_) {}
+  Act alloc(int H, int W, int C) {
+    Act a; a.H = H; a.W = W; a.C = C;
+    a.p = c->arena.alloc((size_t)B * H * W * C);
+    if (!a.p && !rc) rc = fail(c, "workspace too small (need more than %zu bytes)", c->arena.cap);
+    return a;
+  }
+  void free(Act& a) { c->arena.release(a.p); a.p = nullptr; }
+  // gated conv layer: consumes (and releases, if `rel`) `in`
+  Act conv(const char* name, Act& in, bool rel = true, const float* src1 = nullptr, int C1 = 0, int vec = 0) {
+    Act out;
+    if (rc) return out;
+    Layer& L = net.at(name);
+    int Ho = 0, Wo = 0;
+    // dry pass to get shape
+    bool dry = c->dry; c->dry = true;
+    run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, in.H, in.W, &Ho, &Wo);
+    c->dry = dry;
+    out = alloc(Ho, Wo, L.def.cout / 2);
+    if (rc) return out;
+    if (!c->dry) rc = run_gconv(c, L, in.p, in.C, src1, C1, vec, out.p, B, in.H, in.W, nullptr, nullptr);
+    if (rel) free(in);
+    return out;
+  }
+};
+
+// encoder: conv1 (5x5) .. conv10_atrous; returns conv10 output, optionally keeps conv9's
+Act encoder(Plan& P, const std::string& p, Act& in, Act* keep9) {
+  Act x = P.conv((p + "1").c_str(), in);
+  x = P.conv((p + "2_downsample").c_str(), x);
+  x = P.conv((p + "3").c_str(), x);
+  x = P.conv((p + "4_downsample").c_str(), x);
+  x = P.conv((p + "5").c_str(), x);
+  x = P.conv((p + "6").c_str(), x);
+  x = P.conv((p + "7_atrous").c_str(), x);
+  x = P.conv((p + "8_atrous").c_str(), x);
+  Act x9 = P.conv((p + "9_atrous").c_str(), x);
+  Act x10 = P.conv((p + "10_atrous").c_str(), x9, keep9 == nullptr);
+  if (keep9) *keep9 = x9;
+  return x10;
+}
+
+// decoder conv11..conv16 (returns the 12-channel full-resolution activation feeding conv17)
+Act decoder(Plan& P, const std::string& p, Act& in, const float* src1 = nullptr, int C1 = 0, int vec = 0) {
+  Act x = P.conv((p + "11").c_str(), in, true, src1, C1, vec);
+  x = P.conv((p + "12").c_str(), x);
+  x = P.conv((p + "13_upsample_conv").c_str(), x);
+  x = P.conv((p + "14").c_str(), x);
+  x = P.conv((p + "15_upsample_conv").c_str(), x);
+  x = P.conv((p + "16").c_str(), x);
+  return x;
+}
+
+int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* hard, const float* img,
+          const float* mask, float* xnow, float* composed, int no_mask_coarse) {
+  if (P.rc) return P.rc;
+  se_ctx* c = P.c;
+  if (!c->dry) {
+    Layer& L = P.net.at(name);
+    if (!L.packed) return P.rc = fail(c, "layer %s: weights not loaded", name);
+    SmallConvParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.x = in.p; sp.w = L.d_w; sp.b = L.d_b; sp.B = P.B; sp.H = in.H; sp.W = in.W; sp.cout = L.def.cout;
+    sp.mode = mode; sp.out_nchw = out_nchw; sp.hard = hard; sp.img = img; sp.mask = mask; sp.xnow = xnow;
+    sp.composed = composed; sp.no_mask_coarse = no_mask_coarse;
+    hipError_t e = launch_small_conv(sp, c->st);
+    if (e != hipSuccess) return P.rc = fail(c, "small conv %s: %s", name, hipGetErrorString(e));
+  }
+  P.free(in);
+  return 0;
+}
+
+// MDGenerator.forward, editline2_g.py:59-94
+int plan_netM(se_ctx* c, const float* image, const float* sketch, float* mask_out, float* hard_out, float* maskim_out,
+              int B, int H, int W) {
+  Plan P(c, c->M, B);
+  Act in = P.alloc(H, W, 4);
+  if (P.rc) return P.rc;
+  if (!c->dry) HIPCHK(c, launch_pack_m(image, sketch, in.p, B, H, W, c->st));
+  Act x9;
+  const bool want_img = maskim_out != nullptr;
+  Act x10 = encoder(P, "conv", in, want_img ? &x9 : nullptr);
+  if (want_img) {   // image decoder consumes conv9's output (quirk, editline2_g.py:76-77)
+    Act d = decoder(P, "conv", x9);
+    small(P, "conv17", d, 1, maskim_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  }
+  Act d = decoder(P, "conv_mask_", x10);
+  small(P, "conv_mask_17", d, 0, mask_out, hard_out, nullptr, nullptr, nullptr, nullptr, 0);
+  return P.rc;
+}
+
+int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, float* similar_nchw);
+
+// DeepFillC2Generator.forward, editline_g.py:119-221
+int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
+              float* coarse_out, float* fine_out, const float* soft_mask, float* composed_out, int B, int H, int W,
+              int flags) {
+  Plan P(c, c->G, B);
+  const int joint = (flags & SE_FLAG_JOINT_TRAIN_INP) ? 1 : 0;
+  Act cin = P.alloc(H, W, 8), sin = P.alloc(H, W, 8);
+  if (P.rc) return P.rc;
+  if (!c->dry)
+    HIPCHK(c, launch_pack_g(x, x2, mask, mask2, guide, cin.p, sin.p, B, H, W, (flags & SE_FLAG_NO_MASK_CC) ? 1 : 0,
+                            joint, c->st));
+  Act xc = encoder(P, "conv", cin, nullptr);        // :138-147
+  Act xs = encoder(P, "wconv", sin, nullptr);       // :149-158
+  // global pool of the style branch -> (B,96) vector, consumed as second (spatially constant) source
+  Act part = P.alloc(1, COLREDUCE_SPLITS, 96), vec = P.alloc(1, 1, 96);
+  if (P.rc) return P.rc;
+  if (!c->dry)
+    HIPCHK(c, launch_colreduce(xs.p, part.p, vec.p, B, xs.H * xs.W, 96, (flags & SE_FLAG_POOL_MAX) ? 0 : 1, c->st));
+  P.free(xs);
+  P.free(part);
+  Act d = decoder(P, "conv", xc, vec.p, 96, 1);     // :167-175 (cat is virtual)
+  P.free(vec);
+  Act xnow = P.alloc(H, W, 4);
+  if (P.rc) return P.rc;
+  small(P, "conv17", d, 2, coarse_out, nullptr, x, mask, xnow.p, nullptr, (flags & SE_FLAG_NO_MASK_COARSE) ? 1 : 0);
+  if (P.rc) return P.rc;
+  // hallucination branch :184-194
+  Act hcur = P.conv("xconv1", xnow, false);
+  hcur = P.conv("xconv2_downsample", hcur);
+  hcur = P.conv("xconv3", hcur);
+  hcur = P.conv("xconv4_downsample", hcur);
+  hcur = P.conv("xconv5", hcur);
+  hcur = P.conv("xconv6", hcur);
+  hcur = P.conv("xconv7_atrous", hcur);
+  hcur = P.conv("xconv8_atrous", hcur);
+  hcur = P.conv("xconv9_atrous", hcur);
+  Act hallu = P.conv("xconv10_atrous", hcur);
+  // patch-match branch :197-209
+  Act pm = P.conv("pmconv1", xnow);
+  pm = P.conv("pmconv2_downsample", pm);
+  pm = P.conv("pmconv3", pm);
+  pm = P.conv("pmconv4_downsample", pm);
+  pm = P.conv("pmconv5", pm);
+  pm = P.conv("pmconv6", pm);
+  if (flags & SE_FLAG_USE_CAM) {
+    Act att = P.alloc(pm.H, pm.W, 96);
+    if (P.rc) return P.rc;
+    if (run_attention(c, P, pm, mask, att, nullptr)) return P.rc ? P.rc : 1;
+    P.free(pm);
+    pm = att;
+  }
+  pm = P.conv("pmconv9", pm);
+  pm = P.conv("pmconv10", pm);
+  if (P.rc) return P.rc;
+  Act d2 = decoder(P, "allconv", hallu, pm.p, 96, 0);   // cat([x_hallu, pm]) :211 is virtual
+  P.free(pm);
+  small(P, "allconv17", d2, 3, fine_out, nullptr, x, soft_mask, nullptr, soft_mask ? composed_out : nullptr, 0);
+  return P.rc;
+}
+
+int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, float* similar_nchw) {
+  const int h = x.H, w = x.W, B = P.B;
+  const int hs = (h - 4) / 2 + 1, ws = (w - 4) / 2 + 1, L = hs * ws, Lp = (L + 31) & ~31;
+  Act part = P.alloc(1, COLREDUCE_SPLITS, 96), rn = P.alloc(1, 1, 96), xn = P.alloc(h, w, 96);
+  Act valid, S;
+  valid.p = c->arena.alloc((size_t)B * Lp);
+  S.p = c->arena.alloc((size_t)B * L * Lp);
+  if (!part.p || !rn.p || !xn.p || !valid.p || !S.p) return P.rc = fail(c, "workspace too small (attention)");
+  if (!c->dry) {
+    HIPCHK(c, launch_colreduce(x.p, part.p, rn.p, B, h * w, 96, 2, c->st));
+    AttParams a;
+    memset(&a, 0, sizeof a);
+    a.x = x.p; a.rn = rn.p; a.xn = xn.p; a.hard = mask_full; a.valid = valid.p; a.S = S.p; a.out = out.p;
+    a.zeros = c->zeros; a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.L = L; a.Lp = Lp;
+    a.scale = 10.f; a.th = 0.1f;                        // editline_g.py:35-38
+    HIPCHK(c, launch_attention(a, c->st));
+    if (similar_nchw) {
+      // (B, Lk, hs, ws) <- S[b][i][j]: "channel" j, pixel i
+      HIPCHK(c, launch_nhwc_to_nchw(S.p, similar_nchw, B, L, Lp, hs, ws, c->st));
+    }
+  }
+  c->arena.release(S.p); c->arena.release(valid.p);
+  P.free(xn); P.free(rn); P.free(part);
+  return 0;
+}
+
+int check_dims(se_ctx* c, int B, int H, int W) {
+  if (B < 1 || H < 16 || W < 16 || (H % 8) || (W % 8)) return fail(c, "bad shape B=%d H=%d W=%d (H, W must be multiples of 8, >= 16)", B, H, W);
+  return 0;
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+const char* se_version(void) { return "sketchedit_hip 0.1 (gfx950)"; }
+
+int se_create(int device_id, se_ctx** out) {
+  if (!out) return 1;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return fail(nullptr, "no such HIP device %d (count %d)", device_id, n);
+  se_ctx* c = new (std::nothrow) se_ctx();
+  if (!c) return 1;
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&c->zeros, 4096) != hipSuccess ||
+      hipMemset(c->zeros, 0, 4096) != hipSuccess) {
+    delete c;
+    return fail(nullptr, "device init failed");
+  }
+  for (int i = 0; i < NG; ++i) c->G[G_LAYERS[i].name].def = G_LAYERS[i];
+  for (int i = 0; i < NM; ++i) c->M[M_LAYERS[i].name].def = M_LAYERS[i];
+  *out = c;
+  return 0;
+}
+
+void se_destroy(se_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto* net : {&c->G, &c->M})
+    for (auto& kv : *net) {
+      if (kv.second.d_w) (void)hipFree(kv.second.d_w);
+      if (kv.second.d_b) (void)hipFree(kv.second.d_b);
+    }
+  if (c->zeros) (void)hipFree(c->zeros);
+  delete c;
+}
+
+const char* se_last_error(se_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int se_load_weights(se_ctx* c, int net_id, const char* name, const float* host, const int* shape, int ndim) {
+  if (!c || !name || !host || !shape) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  (void)hipSetDevice(c->device);
+  std::string key(name);
+  if (key.rfind("module.", 0) == 0) key = key.substr(7);          // util/util.py:221-222
+  const size_t dot = key.rfind('.');
+  if (dot == std::string::npos) return fail(c, "bad key %s", name);
+  const std::string lname = key.substr(0, dot), kind = key.substr(dot + 1);
+  auto& net = net_id == SE_NET_G ? c->G : c->M;
+  auto it = net.find(lname);
+  if (it == net.end()) return fail(c, "unexpected key %s for net %d", name, net_id);
+  Layer& L = it->second;
+  const LayerDef& d = L.def;
+  if (kind == "weight") {
+    if (ndim != 4 || shape[0] != d.cout || shape[1] != d.cin || shape[2] != d.k || shape[3] != d.k)
+      return fail(c, "size mismatch for %s", name);
+    L.w.assign(host, host + (size_t)d.cout * d.cin * d.k * d.k);
+    L.have_w = true;
+  } else if (kind == "bias") {
+    if (ndim != 1 || shape[0] != d.cout) return fail(c, "size mismatch for %s", name);
+    L.b.assign(host, host + d.cout);
+    L.have_b = true;
+  } else {
+    return fail(c, "unexpected key %s", name);
+  }
+  if (L.have_w && L.have_b) return pack_net_layer(c, L);
+  return 0;
+}
+
+int se_weights_ready(se_ctx* c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  for (auto* net : {&c->G, &c->M})
+    for (auto& kv : *net)
+      if (!kv.second.packed) return 0;
+  return 1;
+}
+
+size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
+  if (!c || check_dims(c, B, H, W)) return 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->dry = true;
+  size_t peak = 0;
+  float dummy;   // non-null marker for optional outputs
+  c->arena.reset(nullptr, 0, true);
+  plan_netM(c, nullptr, nullptr, nullptr, nullptr, &dummy, B, H, W);
+  peak = c->arena.peak;
+  c->arena.reset(nullptr, 0, true);
+  plan_netG(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W,
+            SE_FLAG_USE_CAM | SE_FLAG_POOL_MAX | SE_FLAG_JOINT_TRAIN_INP);
+  if (c->arena.peak > peak) peak = c->arena.peak;
+  c->dry = false;
+  return peak + ((size_t)B * H * W * 4 + 256);   // + hard-mask plane used by se_inference
+}
+
+int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
+                    float* maskim_out, void* ws, size_t ws_bytes, int B, int H, int W) {
+  if (!c) return 1;
+  if (check_dims(c, B, H, W)) return 1;
+  if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->st = (hipStream_t)stream; c->dry = false;
+  c->arena.reset((char*)ws, ws_bytes, false);
+  return plan_netM(c, image, sketch, mask_out, nullptr, maskim_out, B, H, W);
+}
+
+int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, const float* mask, const float* mask2,
+                    const float* guide, float* coarse_out, float* fine_out, void* ws, size_t ws_bytes, int B, int H,
+                    int W, int flags) {
+  if (!c) return 1;
+  if (check_dims(c, B, H, W)) return 1;
+  if (!x || !x2 || !mask || !mask2 || !guide || !fine_out || !ws) return fail(c, "null pointer argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->st = (hipStream_t)stream; c->dry = false;
+  c->arena.reset((char*)ws, ws_bytes, false);
+  return plan_netG(c, x, x2, mask, mask2, guide, coarse_out, fine_out, nullptr, nullptr, B, H, W, flags);
+}
+
+int se_inference(se_ctx* c, void* stream, const float* image, const float* sketch, float* composed_out,
+                 float* mask_out, float* hard_out, float* maskim_out, float* coarse_out, float* fine_out, void* ws,
+                 size_t ws_bytes, int B, int H, int W, int flags) {
+  if (!c) return 1;
+  if (check_dims(c, B, H, W)) return 1;
+  if (!image || !sketch || !composed_out || !mask_out || !ws) return fail(c, "null pointer argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->st = (hipStream_t)stream; c->dry = false;
+  // the hard mask lives at the end of the workspace for the whole call
+  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
+  if (ws_bytes < plane) return fail(c, "workspace too small");
+  float* hard = hard_out ? hard_out : (float*)((char*)ws + ws_bytes - plane);
+  const size_t arena_bytes = ws_bytes - plane;
+  c->arena.reset((char*)ws, arena_bytes, false);
+  int rc = plan_netM(c, image, sketch, mask_out, hard, maskim_out, B, H, W);     // editline2_model.py:339,346-347
+  if (rc) return rc;
+  c->arena.reset((char*)ws, arena_bytes, false);
+  // netG(inputs, inputs, mask_inpaint, mask_inpaint, line)  :366-368 ; composite with the soft mask :132
+  return plan_netG(c, image, image, hard, hard, sketch, coarse_out, fine_out, mask_out, composed_out, B, H, W, flags);
+}
+
+// ---- unit-test entry points (allocate scratch internally; synchronise the stream before freeing) ----
+int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host, const float* b_host, float* y, int B,
+                    int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample) {
+  if (!c || !x || !w_host || !b_host || !y) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->st = (hipStream_t)stream; c->dry = false;
+  Layer L;
+  static const char* nm = "test";
+  L.def = LayerDef{nm, Cin, Cout, k, stride, rate, act, upsample};
+  L.w.assign(w_host, w_host + (size_t)Cout * Cin * k * k);
+  L.b.assign(b_host, b_host + Cout);
+  const int Cp = (Cin + 3) & ~3;
+  float *xin = nullptr, *yout = nullptr;
+  int rc = 0;
+  HIPCHK(c, hipMalloc(&xin, (size_t)B * H * W * Cp * 4));
+  rc = launch_nchw_to_nhwc(x, xin, B, Cin, Cp, H, W, c->st) != hipSuccess;
+  const bool raw = (act == ACT_NONE) || Cout == 3;    // utils.py:27
+  if (!rc && raw) {
+    if (k != 3 || Cin != 12 || (Cout != 1 && Cout != 3) || stride != 1 || rate != 1 || upsample) rc = fail(c, "raw conv: only 3x3 12->{1,3}");
+    if (!rc) rc = pack_small(c, L);
+    if (!rc) {
+      SmallConvParams sp;
+      memset(&sp, 0, sizeof sp);
+      sp.x = xin; sp.w = L.d_w; sp.b = L.d_b; sp.B = B; sp.H = H; sp.W = W; sp.cout = Cout; sp.mode = 4;
+      sp.out_nchw = y;
+      rc = launch_small_conv(sp, c->st) != hipSuccess;
+    }
+  } else if (!rc) {
+    if (Cout % 8) rc = fail(c, "gated conv needs Cout %% 8 == 0");
+    if (!rc) rc = pack_layer(c, L, identity_map(Cin));
+    if (!rc) {
+      int Ho, Wo;
+      c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
+      HIPCHK(c, hipMalloc(&yout, (size_t)B * Ho * Wo * (Cout / 2) * 4));
+      rc = run_gconv(c, L, xin, Cp, nullptr, 0, 0, yout, B, H, W, nullptr, nullptr);
+      if (!rc) rc = launch_nhwc_to_nchw(yout, y, B, Cout / 2, Cout / 2, Ho, Wo, c->st) != hipSuccess;
+    }
+  }
+  (void)hipStreamSynchronize(c->st);
+  if (xin) (void)hipFree(xin);
+  if (yout) (void)hipFree(yout);
+  if (L.d_w) (void)hipFree(L.d_w);
+  if (L.d_b) (void)hipFree(L.d_b);
+  return rc;
+}
+
+int se_attention(se_ctx* c, void* stream, const float* x, const float* mask_full, float* out, float* similar_out, int B,
+                 int h, int w) {
+  if (!c || !x || !mask_full || !out) return 1;
+  if (h < 4 || w < 4 || (h % 2) || (w % 2)) return fail(c, "attention: h, w must be even and >= 4");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->st = (hipStream_t)stream; c->dry = false;
+  const int hs = (h - 4) / 2 + 1, ws_ = (w - 4) / 2 + 1, L = hs * ws_, Lp = (L + 31) & ~31;
+  const size_t bytes = ((size_t)B * h * w * 96 * 3 + (size_t)B * L * Lp + (size_t)B * Lp + 64 * 96 * B) * 4 + (1 << 16);
+  char* ws = nullptr;
+  HIPCHK(c, hipMalloc(&ws, bytes));
+  c->arena.reset(ws, bytes, false);
+  Plan P(c, c->G, B);
+  Act xin = P.alloc(h, w, 96), o = P.alloc(h, w, 96);
+  int rc = P.rc;
+  if (!rc) rc = launch_nchw_to_nhwc(x, xin.p, B, 96, 96, h, w, c->st) != hipSuccess;
+  if (!rc) rc = run_attention(c, P, xin, mask_full, o, similar_out);
+  if (!rc) rc = launch_nhwc_to_nchw(o.p, out, B, 96, 96, h, w, c->st) != hipSuccess;
+  (void)hipStreamSynchronize(c->st);
+  (void)hipFree(ws);
+  return rc;
+}
+
+}  // extern "C"

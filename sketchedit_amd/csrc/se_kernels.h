@@ -1,0 +1,96 @@
+// Internal (C++) interface between the host-side forward plan (se_api.hip) and the
+// gfx950 kernels (se_kernels.hip).  Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace se {
+
+// ---------------------------------------------------------------------------------------------
+// Gather-GEMM gated convolution (the hot kernel).
+//   D[n][p] = sum_k Wp[n][k] * X[p][k]   n: packed output channels, p: output pixels,
+//   k: flattened (tap, channel) in 32-float chunks.  X rows are gathered on the fly from
+//   one or two NHWC sources (im2col-free); Wp is packed on the host (se_pack.cpp).
+// ---------------------------------------------------------------------------------------------
+struct GConvParams {
+  const float* src0;   // NHWC [B][Hin][Win][C0]
+  const float* src1;   // optional second source (channel concat): NHWC [B][Hin][Win][C1] or vector [B][C1]
+  const float* wpk;    // packed weights [nch][NP][32] (LDS image, pre-swizzled)
+  const float* bias;   // [NP] in packed-row order
+  float* dst;          // NHWC [B][Ho][Wo][G]
+  const float* zeros;  // >= 16 bytes of zeros (source of out-of-bounds granules)
+  int B, Hin, Win, Ho, Wo;
+  int C0, C1;          // channel counts (row strides, floats)
+  int C0g, CG;         // granules (4 floats) per tap in src0 / in total
+  int T, KW;           // taps, taps per kernel row
+  int stride, dil, pad;
+  int ushift;          // 1: source is read through a nearest x2 upsample (coords >> 1)
+  int Hlim, Wlim;      // validity limits of the pre-shift tap coordinates
+  int src1_vec;        // src1 is a per-batch vector (spatially constant, still zero padded)
+  int nch;             // number of 32-k chunks
+  int G;               // gated (stored) output channels
+  int act;             // 0 ELU, 1 ReLU
+  int total_pix;       // B*Ho*Wo
+};
+
+enum GConvCfg { GC_N192 = 0, GC_N96 = 1, GC_N48 = 2, GC_N24 = 3 };
+// rows (packed output channels) of each config
+static inline int gconv_np(int cfg) { return cfg == GC_N192 ? 192 : cfg == GC_N96 ? 96 : cfg == GC_N48 ? 48 : 32; }
+static inline bool gconv_mixed(int cfg) { return cfg >= GC_N48; }
+
+hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 conv 12 -> {1,3} raw output + fused tanh/sigmoid/composite (final layer of each decoder)
+// ---------------------------------------------------------------------------------------------
+struct SmallConvParams {
+  const float* x;      // NHWC [B][H][W][12]
+  const float* w;      // [COUT][9][12]
+  const float* b;      // [COUT]
+  int B, H, W, cout;
+  int mode;            // 0: sigmoid -> mask (+hard);  1: tanh -> out;  2: tanh -> coarse + xnow;  3: tanh -> fine + composed;  4: raw
+  float* out_nchw;     // mask / maskim / coarse / fine, NCHW (may be null for modes 2,3)
+  float* hard;         // mode 0: (B,1,H,W) thresholded mask (may be null)
+  const float* img;    // NCHW (B,3,H,W)   modes 2,3
+  const float* mask;   // (B,1,H,W)        mode 2: hard mask; mode 3: soft mask
+  float* xnow;         // mode 2: NHWC4 next-stage input
+  float* composed;     // mode 3: NCHW (B,3,H,W) (may be null)
+  int no_mask_coarse;
+};
+hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Elementwise / layout / reductions
+// ---------------------------------------------------------------------------------------------
+// netM input: [image(3), sketch(1)] NCHW -> NHWC4
+hipError_t launch_pack_m(const float* image, const float* sketch, float* dst4, int B, int H, int W, hipStream_t st);
+// netG inputs: coarse NHWC8 = [x*(1-m) (3), guide, m, 0,0,0]; style NHWC8 = [x2*m2 (3) (or x2), g2, m2, 0,0,0]
+hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
+                         float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint,
+                         hipStream_t st);
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st);
+// column reduce over pixels: x [B][HW][C] -> out [B][C].  op 0 max, 1 mean, 2 rsqrt(sum(x^2)+1e-8)
+hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st);
+static const int COLREDUCE_SPLITS = 32;
+
+// ---------------------------------------------------------------------------------------------
+// Contextual attention (patch 4, stride 2)
+// ---------------------------------------------------------------------------------------------
+struct AttParams {
+  const float* x;      // NHWC [B][h][w][96]   raw features (queries, values)
+  const float* rn;     // [B][96]  1/sqrt(sum x^2 + 1e-8)
+  float* xn;           // NHWC [B][h][w][96]   workspace: x * rn (keys)
+  const float* hard;   // (B,1,4h,4w) full-resolution hole mask
+  float* valid;        // [B][Lp]  workspace: key validity {0,1}
+  float* S;            // [B][L][Lp] workspace: scores, query-major
+  float* out;          // NHWC [B][h][w][96]
+  const float* zeros;
+  int B, h, w, hs, ws, L, Lp;
+  float scale;         // softmax scale (10)
+  float th;            // validity threshold (0.1)
+};
+hipError_t launch_attention(const AttParams& p, hipStream_t st);
+
+}  // namespace se

@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path (through the C-ABI, sketchedit_amd._lib.Engine) against the golden
+vectors captured from the reference and against the oracle on the same seeded inputs.
+
+Tolerance: BASELINE.json north_star -- max-abs <= 1e-3 in fp32 against the reference CPU forward.
+Per-op tests use tighter bounds (1e-4) since no depth amplification is involved.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sketchedit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_E2E = 1e-3
+TOL_OP = 1e-4
+FLAGS = 1 | 2 | 16   # use_cam, pool max, joint_train_inp  (test_celeb.sh)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from sketchedit_amd._lib import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_w(eng):
+    eng.load_state_dict("M", synth.make_state_dict("M", 0))
+    eng.load_state_dict("G", synth.make_state_dict("G", 0))
+    assert eng.weights_ready()
+    return eng
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _md(a, b):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    b = b.detach().cpu().numpy() if hasattr(b, "detach") else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+OPS = [("c3_s1_d1_elu", 8, 16, 3, 1, 1, "elu", 12, 16), ("c3_s2_d1_elu", 8, 16, 3, 2, 1, "elu", 12, 16),
+       ("c3_s1_d2_elu", 8, 16, 3, 1, 2, "elu", 12, 16), ("c3_s1_d16_elu", 8, 16, 3, 1, 16, "elu", 20, 24),
+       ("c3_s1_d1_relu", 8, 16, 3, 1, 1, "relu", 12, 16), ("c3_s1_d1_none", 12, 1, 3, 1, 1, None, 12, 16),
+       ("c3_s1_d1_rgb", 12, 3, 3, 1, 1, "elu", 12, 16), ("c5_s1_d1_elu", 5, 16, 5, 1, 1, "elu", 12, 16)]
+
+
+@pytest.mark.parametrize("case", OPS, ids=[c[0] for c in OPS])
+def test_op_gated_conv_golden(eng, golden_dir, case):
+    name, cin, cout, k, s, r, act, H, W = case
+    g = _load(golden_dir, "ops.npz")
+    w = synth.uniform(7, name + ".w", (cout, cin, k, k), -0.5, 0.5)
+    b = synth.uniform(7, name + ".b", (cout,), -0.5, 0.5)
+    x = synth.uniform(7, name + ".x", (2, cin, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=s, rate=r, act=act)
+    assert _md(y, g["op." + name]) < TOL_OP
+
+
+def test_op_deconv_golden(eng, golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    w = synth.uniform(7, "deconv.w", (16, 8, 3, 3), -0.5, 0.5)
+    b = synth.uniform(7, "deconv.b", (16,), -0.5, 0.5)
+    x = synth.uniform(7, "deconv.x", (2, 8, 6, 8), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, upsample=True)
+    assert _md(y, g["op.deconv"]) < TOL_OP
+
+
+# every (Cin, Cout, stride, rate, up) shape class of the network, ragged sizes, vs the oracle
+NET_SHAPES = [(96, 192, 1, 1, False, 3), (96, 192, 1, 16, False, 3), (96, 192, 1, 4, False, 3),
+              (192, 192, 1, 1, False, 3), (48, 192, 2, 1, False, 3), (48, 192, 1, 1, False, 3),
+              (48, 96, 1, 1, False, 3), (24, 96, 2, 1, False, 3), (24, 96, 1, 1, False, 3),
+              (96, 96, 1, 1, True, 3), (48, 48, 1, 1, True, 3), (24, 48, 2, 1, False, 3),
+              (48, 96, 2, 1, False, 3), (24, 24, 1, 1, False, 3), (4, 48, 1, 1, False, 5),
+              (5, 48, 1, 1, False, 5), (3, 48, 1, 1, False, 5)]
+
+
+@pytest.mark.parametrize("shape", NET_SHAPES, ids=["%d-%d-s%d-d%d-u%d-k%d" % s for s in NET_SHAPES])
+def test_op_gated_conv_network_shapes(eng, shape):
+    from oracle import sketchedit_oracle as O
+    cin, cout, s, r, up, k = shape
+    H, W = (10, 14) if up else (22, 18)          # ragged: not a multiple of the pixel tile
+    a = 1.5 / np.sqrt(cin * k * k)
+    w = synth.uniform(11, "ns.w%s" % (shape,), (cout, cin, k, k), -a, a)
+    b = synth.uniform(11, "ns.b%s" % (shape,), (cout,), -0.3, 0.3)
+    x = synth.uniform(11, "ns.x%s" % (shape,), (3, cin, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=s, rate=r, upsample=up)
+    tw, tb, tx = torch.from_numpy(w), torch.from_numpy(b), torch.from_numpy(x)
+    ref = O.gated_deconv(tx, tw, tb) if up else O.gated_conv(tx, tw, tb, s, r, "elu")
+    assert _md(y, ref) < TOL_OP
+
+
+def test_op_attention_vs_oracle(eng):
+    from oracle import sketchedit_oracle as O
+    x = synth.uniform(5, "att96.x", (2, 96, 12, 16), -1, 1)
+    full = (synth.uniform(5, "att96.m", (2, 1, 48, 64), 0, 1) < 0.6).astype(np.float32)
+    full[1, :, :24] = 1.0
+    full[0, :, 0:16, 0:16] = 1.0
+    out, sim = eng.attention(_cuda(x), _cuda(full), want_similar=True)
+    ro, rp = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
+    ms = torch.nn.functional.avg_pool2d(torch.from_numpy(full), 4, 4)
+    valid = torch.nn.functional.unfold(1 - ms, 4, stride=2).mean(1)
+    assert (valid <= 0.1).any() and (valid > 0.1).any()
+    assert _md(sim, rp) < 1e-5
+    assert _md(out, ro) < TOL_OP
+
+
+def test_op_attention_all_invalid(eng):
+    from oracle import sketchedit_oracle as O
+    x = synth.uniform(5, "att96b.x", (1, 96, 8, 8), -1, 1)
+    ones = np.ones((1, 1, 32, 32), np.float32)
+    out, sim = eng.attention(_cuda(x), _cuda(ones), want_similar=True)
+    ro, rp = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(ones))
+    assert _md(sim, rp) < 1e-6
+    assert _md(out, ro) < TOL_OP
+
+
+def test_netM_64_golden(eng_w, golden_dir):
+    g = _load(golden_dir, "e2e_64.npz")
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    mask, mim = eng_w.netM(_cuda(img), _cuda(sk))
+    assert _md(mask, g["mask"]) < TOL_E2E
+    assert _md(mim, g["mask_image"]) < TOL_E2E
+
+
+def test_netG_64_golden(eng_w, golden_dir):
+    """netG is fed the reference's hard mask so the comparison is independent of threshold flips."""
+    g = _load(golden_dir, "e2e_64.npz")
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    hard = _cuda(g["hard_mask"])
+    ci, cs = _cuda(img), _cuda(sk)
+    coarse, fine = eng_w.netG(ci, ci, hard, hard, cs, FLAGS)
+    assert _md(coarse, g["coarse"]) < TOL_E2E
+    assert _md(fine, g["fine"]) < TOL_E2E
+
+
+def test_inference_64_golden(eng_w, golden_dir):
+    g = _load(golden_dir, "e2e_64.npz")
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    r = eng_w.inference(_cuda(img), _cuda(sk), FLAGS, visualize=True)
+    flips = int((r["hard"].cpu().numpy() != g["hard_mask"]).sum())
+    assert _md(r["mask"], g["mask"]) < TOL_E2E
+    assert flips == 0, "hard-mask flips: %d" % flips
+    for k in ("composed", "coarse", "fine"):
+        assert _md(r[k], g[k]) < TOL_E2E, k
+    assert _md(r["maskim"], g["mask_image"]) < TOL_E2E
+
+
+def test_inference_nonsquare_golden(eng_w, golden_dir):
+    g = _load(golden_dir, "e2e_40x72.npz")
+    img, sk = synth.make_inputs(1, 40, 72, seed=99)
+    r = eng_w.inference(_cuda(img), _cuda(sk), FLAGS, visualize=True)
+    assert int((r["hard"].cpu().numpy() != g["hard_mask"]).sum()) == 0
+    for k in ("composed", "mask", "coarse", "fine"):
+        assert _md(r[k], g[k]) < TOL_E2E, k
+
+
+@pytest.mark.parametrize("tag,flags", [("avg", 1 | 16), ("nocam", 2 | 16), ("nomaskcc", 1 | 2 | 4 | 16),
+                                        ("nomaskcoarse", 1 | 2 | 8 | 16), ("nojoint", 1 | 2)])
+def test_flag_variants_golden(eng_w, golden_dir, tag, flags):
+    from oracle import sketchedit_oracle as O
+    g = _load(golden_dir, "variants_64.npz")
+    img, sk = synth.make_inputs(1, 64, 64, seed=1234)
+    WM = synth.make_state_dict("M", 0)
+    with torch.no_grad():
+        mask, _ = O.netM_forward(WM, img, sk, want_image=False)
+    hard = (mask > 0.5).float().cuda()
+    ci, cs = _cuda(img), _cuda(sk)
+    coarse, fine = eng_w.netG(ci, ci, hard, hard, cs, flags)
+    assert _md(coarse, g[tag + ".coarse"]) < TOL_E2E
+    assert _md(fine, g[tag + ".fine"]) < TOL_E2E
+
+
+def test_inference_256_golden(eng_w, golden_dir):
+    g = _load(golden_dir, "e2e_256.npz")
+    img, sk = synth.make_inputs(1, 256, 256, seed=1234)
+    r = eng_w.inference(_cuda(img), _cuda(sk), FLAGS, visualize=True)
+    hard = r["hard"].cpu().numpy()
+    ref_hard = np.unpackbits(g["hard_mask_bits"])[: hard.size].reshape(hard.shape).astype(np.float32)
+    flips = int((hard != ref_hard).sum())
+    assert flips == 0, "hard-mask flips: %d" % flips
+    for k in ("composed", "mask", "coarse", "fine"):
+        crop = r[k][:, :, 96:160, 96:160]
+        assert _md(crop, g[k + "_crop"]) < TOL_E2E, k
+        a = r[k].double().cpu().numpy()
+        s = np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.min(), a.max()])
+        np.testing.assert_allclose(s, g[k + "_sum"], rtol=2e-3, atol=2e-2)
+
+
+def test_batch_shard_invariance(eng_w):
+    """Image k gives the same result whichever batch (position) computes it -- the property the
+    multi-GPU batch sharding relies on."""
+    img, sk = synth.make_inputs(4, 64, 64, seed=77)
+    full = eng_w.inference(_cuda(img), _cuda(sk), FLAGS)
+    part = eng_w.inference(_cuda(img[2:3]), _cuda(sk[2:3]), FLAGS)
+    assert torch.equal(full["composed"][2:3], part["composed"])
+    assert torch.equal(full["mask"][2:3], part["mask"])
+
+
+def test_full_size_properties(eng_w):
+    """BASELINE config 2 size (256x256, B=32): finite outputs, mask in (0,1), composite identity and
+    per-image agreement with a B=1 run of the same image (size-independent properties)."""
+    img, sk = synth.make_inputs(32, 256, 256, seed=1234)
+    ci, cs = _cuda(img), _cuda(sk)
+    r = eng_w.inference(ci, cs, FLAGS, visualize=True)
+    for k in ("composed", "mask", "fine", "coarse"):
+        assert torch.isfinite(r[k]).all(), k
+    assert float(r["mask"].min()) >= 0 and float(r["mask"].max()) <= 1
+    comp = r["fine"] * r["mask"] + ci * (1 - r["mask"])
+    assert float((comp - r["composed"]).abs().max()) < 1e-6
+    one = eng_w.inference(ci[5:6].contiguous(), cs[5:6].contiguous(), FLAGS)
+    assert torch.equal(one["composed"], r["composed"][5:6])
+
+
+def test_errors(eng_w):
+    from sketchedit_amd._lib import SketchEditHipError
+    img, sk = synth.make_inputs(1, 60, 64, seed=1)     # H not a multiple of 8
+    with pytest.raises(SketchEditHipError):
+        eng_w.inference(_cuda(img), _cuda(sk), FLAGS)
+    with pytest.raises(SketchEditHipError):
+        eng_w.load_state_dict("G", {"nonexistent.weight": np.zeros((1, 1, 3, 3), np.float32)})
+    with pytest.raises(SketchEditHipError):
+        eng_w.load_state_dict("G", {"conv1.weight": np.zeros((48, 4, 5, 5), np.float32)})
