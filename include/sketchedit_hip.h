@@ -74,6 +74,14 @@ int se_inference(se_ctx* ctx, void* stream, const float* image, const float* ske
                  float* mask_out, float* hard_out, float* maskim_out, float* coarse_out, float* fine_out,
                  void* workspace, size_t workspace_bytes, int B, int H, int W, int flags);
 
+/* ---- measurement support (no reference counterpart; used by bench.py) ----------------------------
+ * se_profile_enable(ctx, 1): wrap every kernel launch of subsequent forwards in a pair of HIP events
+ * recorded on the launch stream; se_profile_report synchronises the device and writes a JSON array
+ *   [{"kernel": name, "launches": n, "total_ms": t, "flops": algorithmic FLOPs, "bytes": ...}, ...]
+ * aggregated per kernel.  se_profile_enable(ctx, 0) switches it off and drops the records. */
+int se_profile_enable(se_ctx* ctx, int on);
+int se_profile_report(se_ctx* ctx, char* buf, size_t cap);
+
 /* ---- per-op entry points (unit tests; same kernels as the forwards) ----------------------------
  * gen_conv / gen_deconv (models/networks/utils.py:9-51): x (B,Cin,H,W) device, w (Cout,Cin,k,k) and
  * b (Cout) HOST, y device (B, Cout/2 or Cout, Ho, Wo).  act: 0 ELU, 1 ReLU, 2 None (raw conv).

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsketchedit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["se_kernels.hip", "se_api.hip"]
+SOURCES = ["se_gconv.hip", "se_attention.hip", "se_misc.hip", "se_api.hip"]
 
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
@@ -22,7 +22,7 @@ FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TR
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
            "se_workspace_bytes", "se_netM_forward", "se_netG_forward", "se_inference", "se_gated_conv2d",
-           "se_attention"]
+           "se_attention", "se_profile_enable", "se_profile_report"]
 
 
 class SketchEditHipError(RuntimeError):
@@ -32,7 +32,7 @@ class SketchEditHipError(RuntimeError):
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> sketchedit_amd/lib/libsketchedit_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "se_kernels.h"), os.path.join(_HERE, "..", "include", "sketchedit_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "se_kernels.h"), os.path.join(CSRC, "se_device.h"), os.path.join(_HERE, "..", "include", "sketchedit_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
@@ -83,6 +83,10 @@ def load_library():
         lib.se_gated_conv2d.restype = ci
         lib.se_attention.argtypes = [vp, vp, c_f, c_f, c_f, c_f, ci, ci, ci]
         lib.se_attention.restype = ci
+        lib.se_profile_enable.argtypes = [vp, ci]
+        lib.se_profile_enable.restype = ci
+        lib.se_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
+        lib.se_profile_report.restype = ci
         _lib = lib
         return lib
 
@@ -223,6 +227,17 @@ class Engine:
                                  flags):
             self._err("se_inference")
         return r
+
+    # ---- measurement -----------------------------------------------------------------------------
+    def profile(self, on):
+        self.lib.se_profile_enable(self.h, int(on))
+
+    def profile_report(self):
+        import json
+        buf = ctypes.create_string_buffer(1 << 16)
+        if self.lib.se_profile_report(self.h, buf, len(buf)):
+            self._err("se_profile_report")
+        return json.loads(buf.value.decode())
 
     # ---- per-op entry points (unit tests) --------------------------------------------------------
     def gated_conv2d(self, x, w, b, stride=1, rate=1, act="elu", upsample=False):

@@ -125,6 +125,7 @@ struct se_ctx {
   Arena arena;
   hipStream_t st = nullptr;
   bool dry = false;
+  Profiler prof;
 };
 
 namespace {
@@ -263,9 +264,19 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   p.B = B; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
   p.C0 = C0; p.C1 = C1 ? C1 : C0; p.C0g = C0 / 4; p.CG = L.CGp;
   p.T = L.T; p.KW = d.k; p.stride = d.stride; p.dil = d.rate; p.pad = pad;
+  p.magicCG = (65536 + L.CGp - 1) / L.CGp; p.magicKW = 256 / d.k + 1;
+  for (int gi = 0; gi < L.nch * 8 + 8; ++gi)
+    if (((gi * p.magicCG) >> 16) != gi / L.CGp) return fail(c, "layer %s: magic division check failed", d.name);
+  for (int t = 0; t <= L.T + 8; ++t)
+    if (((t * p.magicKW) >> 8) != t / d.k) return fail(c, "layer %s: magic tap division check failed", d.name);
+  if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) >= 2147483648.0 || (double)B * Ho * Wo * L.G >= 2147483648.0)
+    return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
   p.ushift = d.up ? 1 : 0;
   p.Hlim = d.up ? 2 * Hin : Hin; p.Wlim = d.up ? 2 * Win : Win;
   p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * Ho * Wo;
+  // algorithmic cost as the reference defines the layer (3x3 on the upsampled grid for gen_deconv)
+  set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k,
+                  4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)));
   HIPCHK(c, launch_gconv(L.cfg, p, c->st));
   return 0;
 }
@@ -345,6 +356,8 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
     sp.x = in.p; sp.w = L.d_w; sp.b = L.d_b; sp.B = P.B; sp.H = in.H; sp.W = in.W; sp.cout = L.def.cout;
     sp.mode = mode; sp.out_nchw = out_nchw; sp.hard = hard; sp.img = img; sp.mask = mask; sp.xnow = xnow;
     sp.composed = composed; sp.no_mask_coarse = no_mask_coarse;
+    set_launch_cost(2.0 * (double)P.B * in.H * in.W * L.def.cout * 108.0,
+                    4.0 * (double)P.B * in.H * in.W * (12 + L.def.cout));
     hipError_t e = launch_small_conv(sp, c->st);
     if (e != hipSuccess) return P.rc = fail(c, "small conv %s: %s", name, hipGetErrorString(e));
   }
@@ -568,6 +581,7 @@ int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sk
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   c->st = (hipStream_t)stream; c->dry = false;
+  set_profiler(&c->prof);
   c->arena.reset((char*)ws, ws_bytes, false);
   return plan_netM(c, image, sketch, mask_out, nullptr, maskim_out, B, H, W);
 }
@@ -581,6 +595,7 @@ int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, co
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   c->st = (hipStream_t)stream; c->dry = false;
+  set_profiler(&c->prof);
   c->arena.reset((char*)ws, ws_bytes, false);
   return plan_netG(c, x, x2, mask, mask2, guide, coarse_out, fine_out, nullptr, nullptr, B, H, W, flags);
 }
@@ -594,6 +609,7 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   c->st = (hipStream_t)stream; c->dry = false;
+  set_profiler(&c->prof);
   // the hard mask lives at the end of the workspace for the whole call
   const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
   if (ws_bytes < plane) return fail(c, "workspace too small");
@@ -607,6 +623,43 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   return plan_netG(c, image, image, hard, hard, sketch, coarse_out, fine_out, mask_out, composed_out, B, H, W, flags);
 }
 
+// ---- measurement support (bench.py): per-kernel HIP-event timing ---------------------------------
+int se_profile_enable(se_ctx* c, int on) {
+  if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  c->prof.recs.clear();
+  c->prof.on = on != 0;
+  return 0;
+}
+
+int se_profile_report(se_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap < 64) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  double ms[PL_COUNT] = {0}, fl[PL_COUNT] = {0}, by[PL_COUNT] = {0};
+  long n[PL_COUNT] = {0};
+  for (auto& r : c->prof.recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.label] += t; fl[r.label] += r.flops; by[r.label] += r.bytes; n[r.label]++; }
+  }
+  std::string s = "[";
+  bool first = true;
+  for (int l = 0; l < PL_COUNT; ++l) {
+    if (!n[l]) continue;
+    char t[256];
+    snprintf(t, sizeof t, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+             first ? "" : ", ", prof_label_name(l), n[l], ms[l], fl[l], by[l]);
+    s += t;
+    first = false;
+  }
+  s += "]";
+  if (s.size() + 1 > cap) return fail(c, "profile buffer too small");
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return 0;
+}
+
 // ---- unit-test entry points (allocate scratch internally; synchronise the stream before freeing) ----
 int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host, const float* b_host, float* y, int B,
                     int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample) {
@@ -614,6 +667,7 @@ int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   c->st = (hipStream_t)stream; c->dry = false;
+  set_profiler(&c->prof);
   Layer L;
   static const char* nm = "test";
   L.def = LayerDef{nm, Cin, Cout, k, stride, rate, act, upsample};
@@ -661,6 +715,7 @@ int se_attention(se_ctx* c, void* stream, const float* x, const float* mask_full
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   c->st = (hipStream_t)stream; c->dry = false;
+  set_profiler(&c->prof);
   const int hs = (h - 4) / 2 + 1, ws_ = (w - 4) / 2 + 1, L = hs * ws_, Lp = (L + 31) & ~31;
   const size_t bytes = ((size_t)B * h * w * 96 * 3 + (size_t)B * L * Lp + (size_t)B * Lp + 64 * 96 * B) * 4 + (1 << 16);
   char* ws = nullptr;

@@ -1,0 +1,300 @@
+// Contextual attention (patch 4x4, stride 2) on gfx950.
+//
+// Reference: ReduceContextAttentionP1/P2, /root/reference/models/networks/splitcam.py:37-108,132-153,
+// configured at models/networks/editline_g.py:35-42 and called at :203-207 with f = b = x:
+//   xn      = x / sqrt(sum_hw x^2 + 1e-8)                      per (batch, channel)        :40
+//   S[j,i]  = <patch_j(xn), patch_i(x)>                        keys j, queries i, d = 16*96 :42-44,69
+//   S[j,i] *= (mean over patch j of (1 - avgpool4(mask)) > 0.1)  multiplicative zero        :49-53,90,104
+//   P       = softmax_j(10 * S)                                                            :105
+//   out     = fold(P^T V), V = raw patches of x, overlap-add without normalisation        :138-153
+// Three kernels: scores (gather-GEMM, both operands gathered from NHWC x / xn, written query-major
+// so the softmax axis is contiguous), row softmax, and P.V fused with the fold as a gather: an output
+// pixel of parity class (py,px) sums the <=4 patches covering it, i.e. one GEMM with
+// K = 4 (covering patch) x L (keys) -- deterministic, no atomics.
+#include "se_device.h"
+
+namespace se {
+
+__global__ void att_prep_kernel(const AttParams p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nx = (long)p.B * p.h * p.w * 24;    // granules
+  if (idx < nx) {
+    const int cg = idx % 24;
+    const long pix = idx / 24;
+    const int b = pix / (p.h * p.w);
+    const f32x4 v = *(const f32x4*)(p.x + idx * 4);
+    const f32x4 r = *(const f32x4*)(p.rn + b * 96 + cg * 4);
+    *(f32x4*)(p.xn + idx * 4) = v * r;
+  }
+  if (idx < (long)p.B * p.Lp) {
+    const int b = idx / p.Lp, j = idx - (long)b * p.Lp;
+    float val = 0.f;
+    if (j < p.L) {
+      const int jy = j / p.ws, jx = j - jy * p.ws;
+      const int H = p.h * 4, W = p.w * 4;
+      // the 4x4 patch of the avg-pooled map covers a 16x16 full-resolution window; for a {0,1} mask the
+      // sum is an integer <= 256, so the mean is exact and the > 0.1 test is order independent
+      float hole = 0.f;
+      for (int yy = 0; yy < 16; ++yy)
+        for (int xx = 0; xx < 16; ++xx) hole += p.hard[((long)b * H + jy * 8 + yy) * W + jx * 8 + xx];
+      const float mm = 1.f - hole * (1.f / 256.f);
+      val = mm > p.th ? 1.f : 0.f;
+    }
+    p.valid[idx] = val;
+  }
+}
+
+// S[b][i][j] = scale * valid[j] * <K_j, Q_i>
+template <int NT, int PT>
+__global__ __launch_bounds__(256) void att_score_kernel(const AttParams p) {
+  constexpr int PIX = PT * 64, NP = NT * 16;
+  constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
+  constexpr int NX = PT * 2, NW = (NT * 2 + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  char* Wb = smem + 2 * XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
+  // element offset of the patch origin of a query / key row, or -1
+  auto origin = [&](int i) {
+    if (i >= p.L) return -1;
+    const int py = i / p.ws, px = i - py * p.ws;
+    return ((b * p.h + 2 * py) * p.w + 2 * px) * 96;
+  };
+  int qo[NX], ko[NW];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) qo[i] = origin(q0 + (i * 4 + w) * 8 + (lane >> 3));
+#pragma unroll
+  for (int j = 0; j < NW; ++j) ko[j] = (j * 4 + w) < NT * 2 ? origin(k0 + (j * 4 + w) * 8 + (lane >> 3)) : -1;
+
+  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
+
+  auto stage = [&](int ch, int buf) {
+    const int gi = ch * 8 + s_log;                 // granule of the 16 taps x 24 channel-groups
+    const int tap = (gi * 2731) >> 16, cg = gi - tap * 24;      // gi / 24 for gi < 4096
+    const int doff = ((tap >> 2) * p.w + (tap & 3)) * 96 + cg * 4;
+    const unsigned xdst = lds_x + buf * XBYTES, wdst = lds_w + buf * WBYTES;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const float* g = qo[i] >= 0 ? p.x + (qo[i] + doff) : p.zeros;
+      glds16(g, xdst + (i * 4 + w) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int rbk = j * 4 + w;
+      const float* g = ko[j] >= 0 ? p.xn + (ko[j] + doff) : p.zeros;
+      if (rbk < NT * 2) glds16(g, wdst + rbk * 1024);
+    }
+  };
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NCH = 48;   // 16 taps * 96 ch / 32
+  stage(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < NCH) stage(ch + 1, buf ^ 1);
+    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    dma_wait_all();
+    __syncthreads();
+  }
+  const int q = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int j = k0 + nt * 16 + q * 4;
+    if (j >= p.Lp) continue;
+    const f32x4 v = *(const f32x4*)(p.valid + (long)b * p.Lp + j);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int i = q0 + (w * PT + pt) * 16 + (lane & 15);
+      if (i < p.L) *(f32x4*)(p.S + ((long)b * p.L + i) * p.Lp + j) = acc[nt][pt] * v * p.scale;
+    }
+  }
+}
+
+// softmax over keys j < L of each query row; pad columns [L, Lp) are set to 0.  One wave per row.
+__global__ __launch_bounds__(256) void att_softmax_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)p.B * p.L) return;
+  float* s = p.S + row * p.Lp;
+  float m = -INFINITY;
+  for (int j = lane; j < p.L; j += 64) m = fmaxf(m, s[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float sum = 0.f;
+  for (int j = lane; j < p.L; j += 64) {
+    const float e = expf(s[j] - m);
+    s[j] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  for (int j = lane; j < p.Lp; j += 64) s[j] = j < p.L ? s[j] * inv : 0.f;
+}
+
+// out[b, pos, c] = sum over the <=4 patches covering pos of sum_j P[i][j] * x[b, 2j + (ky,kx), c]
+template <int PT>
+__global__ __launch_bounds__(256) void att_pv_kernel(const AttParams p) {
+  constexpr int NT = 6;
+  constexpr int PIX = PT * 64;
+  constexpr int XBYTES = PIX * 128, VBYTES = 32 * 384;
+  constexpr int NX = PT * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;                        // P tiles  [PIX][32 keys]
+  char* Vb = smem + 2 * XBYTES;           // V tiles  [32 keys][96 ch]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, cls = blockIdx.y, py = cls >> 1, px = cls & 1;
+  const int ch_ = p.h >> 1, cw_ = p.w >> 1;      // class image size
+  const int t0 = blockIdx.x * PIX;
+  int ryx[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int r = t0 + (i * 4 + w) * 8 + (lane >> 3);
+    ryx[i] = r < ch_ * cw_ ? (((r / cw_) << 16) | (r % cw_)) : 0x40000000;
+  }
+  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const unsigned lds_x = lds_addr_of(Xb), lds_v = lds_addr_of(Vb);
+  const int jchunks = p.Lp >> 5;
+  const int nch = 4 * jchunks;
+  // V staging role: 3 pieces per wave; piece it -> granule gidx = it*64 + lane -> key row jr, channel group cg
+  int vjr[3], vcg[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int gidx = (k * 4 + w) * 64 + lane;
+    vjr[k] = gidx / 24;
+    vcg[k] = gidx - vjr[k] * 24;
+  }
+
+  auto stage = [&](int ch, int buf) {
+    const int combo = ch / jchunks, jc = ch - combo * jchunks;      // uniform
+    const int a = combo >> 1, bb = combo & 1;
+    const unsigned xdst = lds_x + buf * XBYTES, vdst = lds_v + buf * VBYTES;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int iy = (ryx[i] >> 16) - a, ix = (ryx[i] & 0xffff) - bb;
+      const bool ok = ((unsigned)iy < (unsigned)p.hs) & ((unsigned)ix < (unsigned)p.ws);
+      const float* g = p.S + ((size_t)((unsigned)(b * p.L + iy * p.ws + ix)) * p.Lp + jc * 32 + s_log * 4);
+      g = ok ? g : p.zeros;
+      glds16(g, xdst + (i * 4 + w) * 1024);
+    }
+    // V tile: key j -> pixel (2jy + py + 2a, 2jx + px + 2bb), 96 channels = 24 granules
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = jc * 32 + vjr[k];
+      const int jy = j / p.ws, jx = j - jy * p.ws;
+      const float* g = p.x + ((size_t)((unsigned)((b * p.h + 2 * jy + py + 2 * a) * p.w + 2 * jx + px + 2 * bb)) * 96 + vcg[k] * 4);
+      g = j < p.L ? g : p.zeros;
+      glds16(g, vdst + (k * 4 + w) * 1024);
+    }
+  };
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) stage(ch + 1, buf ^ 1);
+    const char* Xt = Xb + buf * XBYTES + w * PT * 2048;
+    const float* Vt = (const float*)(Vb + buf * VBYTES);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int off = half ? off1 : off0;
+      f32x4 xb[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) xb[pt] = *(const f32x4*)(Xt + pt * 2048 + off);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = half * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float a = Vt[j * 96 + nt * 16 + (lane & 15)];
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt)
+            acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[pt][r], acc[nt][pt], 0, 0, 0);
+        }
+      }
+    }
+    dma_wait_all();
+    __syncthreads();
+  }
+  const int q = lane >> 4;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int i = t0 + (w * PT + pt) * 16 + (lane & 15);
+    if (i >= ch_ * cw_) continue;
+    const int yy = i / cw_, xx = i - yy * cw_;
+    float* o = p.out + ((long)(b * p.h + 2 * yy + py) * p.w + 2 * xx + px) * 96;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *(f32x4*)(o + nt * 16 + q * 4) = acc[nt][pt];
+  }
+}
+
+hipError_t launch_attention(const AttParams& p, hipStream_t st) {
+  {
+    const long n = (long)p.B * p.h * p.w * 24;
+    ProfScope ps_(st, PL_ATT_PREP);
+    hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+  }
+  {
+    constexpr int NT = 4, PT = 4;
+    constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+    static bool set = false;
+    if (!set) {
+      hipError_t e = hipFuncSetAttribute((const void*)att_score_kernel<NT, PT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return e;
+      set = true;
+    }
+    dim3 grid((p.L + PT * 64 - 1) / (PT * 64), (p.L + NT * 16 - 1) / (NT * 16), p.B);
+    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 0.0);
+    ProfScope ps_(st, PL_ATT_SCORE);
+    hipLaunchKernelGGL((att_score_kernel<NT, PT>), grid, dim3(256), LDS, st, p);
+  }
+  {
+    const long rows = (long)p.B * p.L;
+    ProfScope ps_(st, PL_ATT_SOFTMAX);
+    hipLaunchKernelGGL(att_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  }
+  {
+    constexpr int PT = 4;
+    constexpr int LDS = 2 * PT * 64 * 128 + 2 * 32 * 384;
+    static bool set = false;
+    if (!set) {
+      hipError_t e = hipFuncSetAttribute((const void*)att_pv_kernel<PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         LDS);
+      if (e != hipSuccess) return e;
+      set = true;
+    }
+    const int cpix = (p.h >> 1) * (p.w >> 1);
+    dim3 grid((cpix + PT * 64 - 1) / (PT * 64), 4, p.B);
+    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 0.0);
+    ProfScope ps_(st, PL_ATT_PV);
+    hipLaunchKernelGGL((att_pv_kernel<PT>), grid, dim3(256), LDS, st, p);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace se

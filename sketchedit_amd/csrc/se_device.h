@@ -1,0 +1,83 @@
+// Device-side helpers shared by the gfx950 kernels: LDS-DMA issue, the 32-k MFMA chunk core,
+// activation math, and the host-side launch profiler scope.
+#pragma once
+#include "se_kernels.h"
+
+namespace se {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define DEVFN __device__ __forceinline__
+
+// ---- LDS-DMA ------------------------------------------------------------------------------------
+// global_load_lds_dwordx4: lane i of the wave writes 16 B at lds_addr + 16*i (lds_addr wave-uniform,
+// in M0).  Issued through inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending LDS
+// write and drains vmcnt(0) in front of every later ds_read (measured: it serialised all staging
+// loads of a chunk with full memory latency).  Hidden from its bookkeeping, the loads of chunk c+1
+// stay in flight under the MFMAs of chunk c; completion is enforced by dma_wait_all() + a barrier
+// before the tile is read.
+DEVFN void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+DEVFN void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+DEVFN unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+DEVFN float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // nn.ELU(), alpha 1
+DEVFN float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---- MFMA core ------------------------------------------------------------------------------------
+// One 32-k chunk for a wave tile of NT (rows: packed channels) x PT (cols: pixels) 16x16 tiles.
+// Wt: [NT*16][128 B] tile, Xt: this wave's [PT*16][128 B] tile, both with the 16-B slot of row r
+// stored at (slot ^ ((r>>1)&7)).  off0/off1 = per-lane byte offsets for k-half 0/1.
+// v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D[i=(lane>>4)*4+reg][j=lane&15].
+template <int NT, int PT>
+DEVFN void mfma_chunk(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const char* __restrict__ Xt, int off0,
+                      int off1) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int off = half ? off1 : off0;
+    f32x4 xb[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xb[pt] = *(const f32x4*)(Xt + pt * 2048 + off);
+    f32x4 wn = *(const f32x4*)(Wt + off);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 wa = wn;
+      if (nt + 1 < NT) wn = *(const f32x4*)(Wt + (nt + 1) * 2048 + off);   // fragment prefetch, one tile ahead
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], xb[pt][r], acc[nt][pt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// per-lane fragment read offsets (see mfma_chunk)
+DEVFN void frag_offsets(int lane, int& off0, int& off1) {
+  const int swz = (lane >> 1) & 7;
+  off0 = (lane & 15) * 128 + (((lane >> 4) ^ swz) << 4);
+  off1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ swz) << 4);
+}
+
+// ---- host: launch profiler scope -------------------------------------------------------------------
+struct ProfScope {
+  hipStream_t st;
+  int idx = -1;
+  ProfScope(hipStream_t s, int label);
+  ~ProfScope();
+};
+
+}  // namespace se

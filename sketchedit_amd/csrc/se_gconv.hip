@@ -1,0 +1,185 @@
+// Gated convolution as a gather-GEMM on the fp32 MFMA (gfx950).
+//
+//   D[n][p] = sum_k Wp[n][k] * X[p][k]     n: packed output channel, p: output pixel,
+//                                           k: flattened (tap, input channel), chunks of 32
+//   out[p][c] = act(D[feat c][p] + b) * sigmoid(D[gate c][p] + b)     (models/networks/utils.py:21-33)
+//
+// A workgroup (4 waves, one per SIMD) owns PT*64 consecutive output pixels (NHWC order) and ALL
+// output channels, so the gate is a register-level epilogue.  Per chunk it stages the [pixels][32]
+// activation tile (gathered: every 16-byte granule is one tap's 4 channels of one input pixel;
+// stride, dilation, nearest-x2 upsampling and zero padding are pure address arithmetic -- padding
+// reads come from a zero page) and the [channels][32] weight tile (host-packed LDS image, linear
+// copy) into LDS with LDS-DMA, double-buffered, one barrier per chunk.  Reference semantics:
+//   gen_conv    models/networks/utils.py:9-33      padding = rate*(k-1)/2, zero padding
+//   gen_deconv  models/networks/utils.py:35-51     nearest x2 (src = dst>>1) then 3x3 conv
+//   concat      models/networks/editline_g.py:166-167,211 (second source = other tensor / pooled vector)
+#include "se_device.h"
+
+namespace se {
+
+template <int NT, int PT, bool MIXED>
+__global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
+  constexpr int PIX = PT * 64;
+  constexpr int NP = NT * 16;
+  constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
+  constexpr int NX = PT * 2;                 // X staging pieces (8 rows each) per wave per chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  char* Wb = smem + 2 * XBYTES;
+  int2* rowtab = (int2*)(smem + 2 * XBYTES + 2 * WBYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_base = blockIdx.x * PIX;
+
+  // ---- row table: (batch, packed y0|x0) of every pixel row of the tile; invalid rows fail the bounds test
+  const int HoWo = p.Ho * p.Wo;
+  for (int r = tid; r < PIX; r += 256) {
+    const int pidx = tile_base + r;
+    int2 e = make_int2(0, 0x40000000);
+    if (pidx < p.total_pix) {
+      const int b = pidx / HoWo, rem = pidx - b * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      e = make_int2(b, ((oy * p.stride) << 16) | (ox * p.stride));
+    }
+    rowtab[r] = e;
+  }
+  __syncthreads();
+  int rb[NX], ryx[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int2 e = rowtab[(i * 4 + w) * 8 + (lane >> 3)];
+    rb[i] = e.x;
+    ryx[i] = e.y;
+  }
+
+  // staging role of this lane: physical slot ps of rows (piece*8 + lane>>3) <-> logical k-slot s_log
+  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
+
+  auto stage = [&](int ch, int buf) {
+    // which granule of the flattened K axis this lane fetches: (tap, 4-channel group)
+    const int gi = ch * 8 + s_log;
+    const int tap = (gi * p.magicCG) >> 16, cg = gi - tap * p.CG;
+    const int ky = (tap * p.magicKW) >> 8, kx = tap - ky * p.KW;
+    const int dy = ky * p.dil - p.pad, dx = kx * p.dil - p.pad;
+    const bool tapok = tap < p.T;
+    const bool first = cg < p.C0g;
+    const float* base = first ? p.src0 : p.src1;
+    const int cs = first ? p.C0 : p.C1;
+    const int coff = (first ? cg : cg - p.C0g) * 4;
+    const bool vec = (!first) && p.src1_vec;
+    const unsigned xdst = lds_x + buf * XBYTES;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      int iy = (ryx[i] >> 16) + dy, ix = (ryx[i] & 0xffff) + dx;
+      const bool ok = tapok & ((unsigned)iy < (unsigned)p.Hlim) & ((unsigned)ix < (unsigned)p.Wlim);
+      iy >>= p.ushift;
+      ix >>= p.ushift;
+      const unsigned pix = vec ? (unsigned)rb[i] : (unsigned)((rb[i] * p.Hin + iy) * p.Win + ix);
+      const float* g = base + (size_t)(pix * (unsigned)cs + (unsigned)coff);
+      g = ok ? g : p.zeros;
+      glds16(g, xdst + (i * 4 + w) * 1024);
+    }
+    const unsigned wdst = lds_w + buf * WBYTES;
+    const float* wsrc = p.wpk + (size_t)ch * NP * 32 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < (NT * 2 + 3) / 4; ++j) {
+      const int rbk = j * 4 + w;
+      if (rbk < NT * 2) glds16(wsrc + rbk * 256, wdst + rbk * 1024);
+    }
+  };
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int ch = 0; ch < p.nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < p.nch) stage(ch + 1, buf ^ 1);                 // DMA of the next chunk flies under the MFMAs
+    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    dma_wait_all();
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, gate, NHWC store (a lane holds 4 consecutive channels of pixel lane&15)
+  const int q = lane >> 4;
+  if (!MIXED) {
+    constexpr int NF = NT / 2;       // tiles [0,NF): features, [NF,NT): matching gates
+#pragma unroll
+    for (int nt = 0; nt < NF; ++nt) {
+      const int c0 = nt * 16 + q * 4;
+      const f32x4 bf = *(const f32x4*)(p.bias + c0);
+      const f32x4 bg = *(const f32x4*)(p.bias + NF * 16 + c0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float f = acc[nt][pt][r] + bf[r];
+          const float g = acc[nt + NF][pt][r] + bg[r];
+          const float a = p.act == 0 ? elu1(f) : fmaxf(f, 0.f);
+          o[r] = a * sigmoidf_(g);
+        }
+        if (c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + (size_t)pidx * p.G + c0) = o;
+      }
+    }
+  } else {
+    // tile rows 0-7: features 8nt..8nt+7 (lanes q=0,1); rows 8-15: the matching gates (lanes q=2,3)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c0 = nt * 8 + (q & 1) * 4;
+      const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[nt][pt][r] + bq[r];
+          const float g = __shfl_xor(v, 32);        // lanes 0-31 receive their gate pre-activation
+          const float a = p.act == 0 ? elu1(v) : fmaxf(v, 0.f);
+          o[r] = a * sigmoidf_(g);
+        }
+        if (q < 2 && c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + (size_t)pidx * p.G + c0) = o;
+      }
+    }
+  }
+}
+
+template <int NT, int PT, bool MIXED>
+static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st) {
+  constexpr int PIX = PT * 64;
+  constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128 + PIX * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gconv_kernel<NT, PT, MIXED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = (p.total_pix + PIX - 1) / PIX;
+  ProfScope ps_(st, NT == 12 ? PL_GCONV_N192 : NT == 6 ? PL_GCONV_N96 : NT == 3 ? PL_GCONV_N48 : PL_GCONV_N24);
+  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED>), dim3(grid), dim3(256), LDS, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
+  switch (cfg) {
+    case GC_N192: return launch_gconv_t<12, 4, false>(p, st);
+    case GC_N96: return launch_gconv_t<6, 4, false>(p, st);
+    case GC_N48: return launch_gconv_t<3, 8, true>(p, st);
+    case GC_N24: return launch_gconv_t<2, 8, true>(p, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace se

@@ -5,7 +5,24 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace se {
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline
+// figures.  Off by default; when off the launch wrappers add nothing.
+// ---------------------------------------------------------------------------------------------
+enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL_SMALL_CONV, PL_PACK, PL_COLREDUCE,
+                 PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
+const char* prof_label_name(int l);
+struct Profiler {
+  struct Rec { int label; double flops; double bytes; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  bool on = false;
+};
+void set_profiler(Profiler* p);          // thread-local; set by the API under the ctx lock
+void set_launch_cost(double flops, double bytes);   // algorithmic cost of the NEXT launch (consumed once)
 
 // ---------------------------------------------------------------------------------------------
 // Gather-GEMM gated convolution (the hot kernel).
@@ -24,6 +41,7 @@ struct GConvParams {
   int C0, C1;          // channel counts (row strides, floats)
   int C0g, CG;         // granules (4 floats) per tap in src0 / in total
   int T, KW;           // taps, taps per kernel row
+  int magicCG, magicKW; // x/CG == (x*magicCG)>>16, t/KW == (t*magicKW)>>8 on the ranges used (host-verified)
   int stride, dil, pad;
   int ushift;          // 1: source is read through a nearest x2 upsample (coords >> 1)
   int Hlim, Wlim;      // validity limits of the pre-shift tap coordinates

@@ -1,0 +1,265 @@
+// Memory-bound helper kernels of the SketchEdit forward (gfx950): final 12->{1,3} convs with fused
+// tanh / sigmoid / composites, input packing (NCHW -> NHWC with masking / concat), layout conversion for
+// the unit-test entry points, deterministic column reductions (global max / mean pool, L2 norm), and the
+// host-side launch profiler.
+#include "se_device.h"
+
+namespace se {
+
+// ---- profiler plumbing ----------------------------------------------------------------------------
+static thread_local Profiler* g_prof = nullptr;
+static thread_local double g_next_flops = 0.0, g_next_bytes = 0.0;
+void set_profiler(Profiler* p) { g_prof = p; }
+void set_launch_cost(double flops, double bytes) { g_next_flops = flops; g_next_bytes = bytes; }
+const char* prof_label_name(int l) {
+  static const char* n[PL_COUNT] = {"gconv_n192", "gconv_n96", "gconv_n48", "gconv_n24", "small_conv", "pack",
+                                    "colreduce", "att_prep", "att_score", "att_softmax", "att_pv", "layout"};
+  return (l >= 0 && l < PL_COUNT) ? n[l] : "?";
+}
+
+ProfScope::ProfScope(hipStream_t s, int label) : st(s) {
+  Profiler* p = g_prof;
+  const double fl = g_next_flops, by = g_next_bytes;
+  g_next_flops = g_next_bytes = 0.0;
+  if (!p || !p->on) return;
+  Profiler::Rec r;
+  r.label = label; r.flops = fl; r.bytes = by;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, st);
+  p->recs.push_back(r);
+  idx = (int)p->recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(g_prof->recs[idx].b, st);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// final 3x3 conv of each decoder: 12 -> COUT raw, + tanh / sigmoid / composites (VALU, memory bound)
+// ------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p) {
+  const int HW = p.H * p.W;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.B * HW) return;
+  const int b = idx / HW, rem = idx - (long)b * HW;
+  const int y = rem / p.W, x = rem - y * p.W;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = p.b[c];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y + ky - 1;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = x + kx - 1;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+        const f32x4* src = (const f32x4*)(p.x + ((long)(b * p.H + iy) * p.W + ix) * 12);
+        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
+        const float v[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+          const float* wc = p.w + (c * 9 + ky * 3 + kx) * 12;
+#pragma unroll
+          for (int i = 0; i < 12; ++i) acc[c] = fmaf(v[i], wc[i], acc[c]);
+        }
+      }
+    }
+  }
+  if (p.mode == 4) {   // raw conv output (unit tests of the passthrough rule, utils.py:27)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) p.out_nchw[((long)b * COUT + c) * HW + rem] = acc[c];
+    return;
+  }
+  if (p.mode == 0) {
+    const float m = sigmoidf_(acc[0]);
+    p.out_nchw[idx] = m;
+    if (p.hard) p.hard[idx] = m > 0.5f ? 1.f : 0.f;
+    return;
+  }
+  if constexpr (COUT == 3) {
+    float t[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = tanhf(acc[c]);
+    if (p.out_nchw) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p.out_nchw[((long)b * 3 + c) * HW + rem] = t[c];
+    }
+    if (p.mode == 2) {
+      const float m = p.mask[idx];
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // xnow = stage1*mask + xin*(1-mask), xin = image*(1-mask)   (editline_g.py:124,179-180)
+        const float xin = p.img[((long)b * 3 + c) * HW + rem] * (1.f - m);
+        o[c] = p.no_mask_coarse ? t[c] : t[c] * m + xin * (1.f - m);
+      }
+      o[3] = 0.f;
+      *(f32x4*)(p.xnow + idx * 4) = o;
+    } else if (p.mode == 3 && p.composed) {
+      const float m = p.mask[idx];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float im = p.img[((long)b * 3 + c) * HW + rem];
+        p.composed[((long)b * 3 + c) * HW + rem] = t[c] * m + im * (1.f - m);   // editline2_model.py:132
+      }
+    }
+  }
+}
+
+hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st) {
+  const long n = (long)p.B * p.H * p.W;
+  const int grid = (int)((n + 255) / 256);
+  ProfScope ps_(st, PL_SMALL_CONV);
+  if (p.cout == 1)
+    hipLaunchKernelGGL(small_conv_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+  else if (p.cout == 3)
+    hipLaunchKernelGGL(small_conv_kernel<3>, dim3(grid), dim3(256), 0, st, p);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing / layout
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_m_kernel(const float* __restrict__ image, const float* __restrict__ sketch,
+                              float* __restrict__ dst, int B, int HW) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW) return;
+  const int b = idx / HW, rem = idx - (long)b * HW;
+  f32x4 o;
+  o[0] = image[((long)b * 3 + 0) * HW + rem];
+  o[1] = image[((long)b * 3 + 1) * HW + rem];
+  o[2] = image[((long)b * 3 + 2) * HW + rem];
+  o[3] = sketch[idx];
+  *(f32x4*)(dst + idx * 4) = o;   // editline2_g.py:62
+}
+hipError_t launch_pack_m(const float* image, const float* sketch, float* dst4, int B, int H, int W, hipStream_t st) {
+  const long n = (long)B * H * W;
+  ProfScope ps_(st, PL_PACK);
+  hipLaunchKernelGGL(pack_m_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, image, sketch, dst4, B, H * W);
+  return hipGetLastError();
+}
+
+__global__ void pack_g_kernel(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ mask,
+                              const float* __restrict__ mask2, const float* __restrict__ guide,
+                              float* __restrict__ coarse8, float* __restrict__ style8, int B, int HW, int no_mask_cc,
+                              int joint) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW) return;
+  const int b = idx / HW, rem = idx - (long)b * HW;
+  const float m = mask[idx], m2 = mask2[idx], g = guide[idx];
+  f32x4 c0, c1, s0, s1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const long o = ((long)b * 3 + c) * HW + rem;
+    c0[c] = x[o] * (1.f - m);                       // editline_g.py:124
+    s0[c] = no_mask_cc ? x2[o] : x2[o] * m2;        // :120-123
+  }
+  c0[3] = g;                                        // :131
+  c1 = (f32x4){m, 0.f, 0.f, 0.f};
+  s0[3] = joint ? g * 0.f : g;                      // :132-135
+  s1 = (f32x4){m2, 0.f, 0.f, 0.f};
+  *(f32x4*)(coarse8 + idx * 8) = c0;
+  *(f32x4*)(coarse8 + idx * 8 + 4) = c1;
+  *(f32x4*)(style8 + idx * 8) = s0;
+  *(f32x4*)(style8 + idx * 8 + 4) = s1;
+}
+hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
+                         float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint,
+                         hipStream_t st) {
+  const long n = (long)B * H * W;
+  ProfScope ps_(st, PL_PACK);
+  hipLaunchKernelGGL(pack_g_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x2, mask, mask2, guide,
+                     coarse8, style8, B, H * W, no_mask_cc, joint);
+  return hipGetLastError();
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int Cpad,
+                                    int HW) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*HW*Cpad
+  if (idx >= (long)B * HW * Cpad) return;
+  const int c = idx % Cpad;
+  const long pix = idx / Cpad;
+  const int b = pix / HW, rem = pix - (long)b * HW;
+  dst[idx] = c < C ? src[((long)b * C + c) * HW + rem] : 0.f;
+}
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st) {
+  const long n = (long)B * H * W * Cpad;
+  ProfScope ps_(st, PL_LAYOUT);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, B, C, Cpad,
+                     H * W);
+  return hipGetLastError();
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int Cs,
+                                    int HW) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*C*HW (NCHW order)
+  if (idx >= (long)B * C * HW) return;
+  const int rem = idx % HW;
+  const long bc = idx / HW;
+  const int c = bc % C, b = bc / C;
+  dst[idx] = src[((long)b * HW + rem) * Cs + c];
+}
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st) {
+  const long n = (long)B * C * H * W;
+  ProfScope ps_(st, PL_LAYOUT);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, B, C, Cstride,
+                     H * W);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// column reduce over pixels (global max pool / mean / L2 norm), deterministic two-stage
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                                int HW, int C, int op) {
+  // grid (SPLITS, B); block 256 threads = (256/C' groups) ... generic: thread t handles channel t%C, pixel lane t/C
+  __shared__ float red[256];
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int per = (HW + COLREDUCE_SPLITS - 1) / COLREDUCE_SPLITS;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const int groups = 256 / C;            // C <= 256
+  const int c = threadIdx.x % C, g = threadIdx.x / C;
+  float a = op == 0 ? -INFINITY : 0.f;
+  if (g < groups) {
+    for (int pp = p0 + g; pp < p1; pp += groups) {
+      const float v = x[((long)b * HW + pp) * C + c];
+      a = op == 0 ? fmaxf(a, v) : (op == 1 ? a + v : fmaf(v, v, a));
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float r = red[threadIdx.x];
+    for (int gg = 1; gg < groups; ++gg) {
+      const float v = red[gg * C + threadIdx.x];
+      r = op == 0 ? fmaxf(r, v) : r + v;
+    }
+    partial[((long)b * COLREDUCE_SPLITS + sp) * C + threadIdx.x] = r;
+  }
+}
+__global__ void colreduce_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int HW, int C, int op,
+                                       int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // over B*C
+  if (idx >= total) return;
+  const int b = idx / C, c = idx - b * C;
+  float r = op == 0 ? -INFINITY : 0.f;
+  for (int sp = 0; sp < COLREDUCE_SPLITS; ++sp) {
+    const float v = partial[((long)b * COLREDUCE_SPLITS + sp) * C + c];
+    r = op == 0 ? fmaxf(r, v) : r + v;
+  }
+  if (op == 1) r = r / (float)HW;
+  if (op == 2) r = 1.f / sqrtf(r + 1e-8f);
+  out[idx] = r;
+}
+hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st) {
+  if (C > 256) return hipErrorInvalidValue;
+  ProfScope ps_(st, PL_COLREDUCE);
+  hipLaunchKernelGGL(colreduce_partial_kernel, dim3(COLREDUCE_SPLITS, B), dim3(256), 0, st, x, partial, HW, C, op);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, partial, out, HW, C, op,
+                     B * C);
+  return hipGetLastError();
+}
+
+}  // namespace se
