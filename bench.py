@@ -43,7 +43,9 @@ LIVE_GFLOP_PER_IMAGE = {256: 90.80, 512: 437.27}
 def cpu_baseline(size, budget_s=20.0):
     """Time the oracle on the host cores: 256x256 batches of 2 until ~budget_s of CPU work is spent."""
     from oracle import sketchedit_oracle as O
-    cores = os.cpu_count() or 1
+    # oneDNN collapses when oversubscribed on the 2x64-core GPU hosts (measured with tools/cpu_probe.py:
+    # 32 threads 10.0 img/s, 64 threads 4.1, 128 threads 1.4, 256 threads 0.03), so cap at 32.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
     WM = {k: torch.from_numpy(v) for k, v in WM.items()}

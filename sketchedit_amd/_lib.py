@@ -91,6 +91,18 @@ def load_library():
         return lib
 
 
+_shared = {}
+_shared_lock = threading.Lock()
+
+
+def shared_engine(device=0):
+    """A process-wide Engine per device for the per-op entry points (no weights involved)."""
+    with _shared_lock:
+        if device not in _shared:
+            _shared[device] = Engine(device)
+        return _shared[device]
+
+
 def flags_from_opt(opt):
     """netG flag word from a reference-style options namespace (editline_g.py:15-23, base_options.py:19)."""
     f = 0

@@ -1,0 +1,27 @@
+"""Dataset registry + loader (reference: /root/reference/data/__init__.py:6-49):
+--dataset_mode <name> -> data/<name>_dataset.py -> class <Name>Dataset."""
+import importlib
+
+import torch.utils.data
+
+
+def find_dataset_using_name(dataset_name):
+    lib = importlib.import_module(__name__ + "." + dataset_name + "_dataset")
+    target = dataset_name.replace("_", "") + "dataset"
+    for name, cls in vars(lib).items():
+        if name.lower() == target.lower() and isinstance(cls, type) and issubclass(cls, torch.utils.data.Dataset):
+            return cls
+    raise ValueError("In %s_dataset.py, there should be a Dataset subclass whose name matches %s in lowercase."
+                     % (dataset_name, target))
+
+
+def get_option_setter(dataset_name):
+    return find_dataset_using_name(dataset_name).modify_commandline_options
+
+
+def create_dataloader(opt):
+    instance = find_dataset_using_name(opt.dataset_mode)()
+    instance.initialize(opt)
+    print("dataset [%s] of size %d was created" % (type(instance).__name__, len(instance)))
+    return torch.utils.data.DataLoader(instance, batch_size=opt.batchSize, shuffle=not opt.serial_batches,
+                                       num_workers=int(opt.nThreads), drop_last=opt.isTrain)

@@ -1,0 +1,85 @@
+"""EditLine2Model: the wrapper test.py / demo.py call (reference: models/editline2_model.py:49-147,
+184-200,223-242,338-370).  Only the inference-side modes exist here ('inference', 'visualize'); the
+training modes of the reference ('generator', 'discriminator') depend on code it never released.
+
+    model = create_model(opt); model.eval()
+    composed, mask = model({'image': (B,3,H,W) in [-1,1], 'mask': (B,1,H,W) sketch in {0,1}}, mode='inference')
+
+inference = netM -> mask_inpaint = (mask > 0.5) -> netG(inputs, inputs, mask_inpaint, mask_inpaint, line)
+-> composed = fake*mask + inputs*(1-mask) with the SOFT mask (:132), all inside one se_inference call.
+"""
+import torch
+
+from .. import _lib
+from ..util import util
+from . import networks
+
+
+class EditLine2Model(torch.nn.Module):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        networks.modify_commandline_options(parser, is_train)
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        if getattr(opt, "isTrain", False):
+            raise NotImplementedError("sketchedit_amd implements the inference path only")
+        self.opt = opt
+        self.netM, self.netG = self.initialize_networks(opt)
+        self._engine = None
+
+    def use_gpu(self):
+        return len(self.opt.gpu_ids) > 0
+
+    def initialize_networks(self, opt):
+        netG = networks.define_G(opt)
+        saved = opt.netG
+        opt.netG = "MD"                                   # editline2_model.py:186-188
+        netM = networks.define_G(opt)
+        opt.netG = saved
+        if not hasattr(opt, "isSkip"):                    # :195-197 (isSkip bypasses the checkpoint load)
+            netG = util.load_network(netG, "G", opt.which_epoch, opt)
+            netM = util.load_network(netM, "M", opt.which_epoch, opt)
+            if self.use_gpu():
+                netG.cuda()
+                netM.cuda()
+        return netM, netG
+
+    def engine(self):
+        if not self.use_gpu() or not torch.cuda.is_available():
+            raise _lib.SketchEditHipError("EditLine2Model: this path needs an MI355X (--gpu_ids 0); the reference's "
+                                          "--gpu_ids -1 CPU mode has no counterpart here")
+        if self._engine is None:
+            self._engine = _lib.Engine(self.opt.gpu_ids[0])
+            self.netG.bind_engine(self._engine)
+            self.netM.bind_engine(self._engine)
+        self.netG.engine()                                # (re)upload weights if they changed
+        self.netM.engine()
+        return self._engine
+
+    def preprocess_input(self, data):
+        """:223-242.  gt / edgegt are filled from image / mask when absent (the reference only does so
+        on the GPU branch and raises KeyError on CPU)."""
+        dev = torch.device("cuda", self.opt.gpu_ids[0]) if self.use_gpu() else torch.device("cpu")
+        data["image"] = data["image"].to(dev)
+        data["gt"] = data["gt"].to(dev) if "gt" in data else data["image"]
+        data["mask"] = data["mask"].to(dev)
+        data["edgegt"] = data["edgegt"].to(dev) if "edgegt" in data else data["mask"]
+        return data["image"], data["gt"], data["mask"], data["edgegt"], None
+
+    def forward(self, data, mode):
+        inputs, real_image, line, line_full, _ = self.preprocess_input(data)
+        if mode not in ("inference", "visualize"):
+            raise ValueError("|mode| is invalid")
+        if self.training:
+            raise NotImplementedError("call model.eval() first: only the eval branch of generate_fake exists here")
+        eng = self.engine()
+        flags = _lib.flags_from_opt(self.opt)
+        with torch.no_grad():
+            r = eng.inference(inputs.float().contiguous(), line.float().contiguous(), flags,
+                              visualize=(mode == "visualize"))
+        if mode == "inference":
+            return r["composed"], r["mask"]
+        return {"mask": r["hard"], "maskim": r["maskim"], "coarse": r["coarse"], "fine": r["fine"],
+                "composed": r["composed"]}                # :134-145

@@ -1,0 +1,42 @@
+"""Batch sharding of the inference path across the GPUs of one node (one process per GPU).
+
+Images are independent (no batch statistics; attention, K-normalisation and pooling are per sample --
+SURVEY.md 8e), so rank r runs rows [lo, hi) of the global batch with replicated weights and no exchange
+during the forward.  The only collective is the all-gather of the outputs (composed (B,3,H,W) and
+mask (B,1,H,W)); on the GPU box the backend is nccl = RCCL over xGMI, in the CPU tests it is gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, world, rank):
+    """Contiguous, balanced shard [lo, hi) of n items for `rank` of `world`."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_batch(local, group=None):
+    """All-gather equally sized batch shards (dim 0) from every rank, in rank order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    else:
+        dist.all_gather(list(out.chunk(world, 0)), local.contiguous(), group=group)
+    return out
+
+
+def sharded_inference(forward, image, sketch, group=None):
+    """Run `forward(image_shard, sketch_shard) -> (composed, mask)` on this rank's rows of the global
+    batch and return the gathered global (composed, mask).  Requires batch % world == 0."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = image.shape[0]
+    if n % world:
+        raise ValueError("global batch %d is not a multiple of the world size %d" % (n, world))
+    lo, hi = shard_range(n, world, rank)
+    composed, mask = forward(image[lo:hi].contiguous(), sketch[lo:hi].contiguous())
+    return gather_batch(composed, group), gather_batch(mask, group)

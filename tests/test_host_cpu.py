@@ -1,0 +1,177 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the host-side mirror of
+the reference interface (options, registries, state_dict contract, dataset), loud failure without a GPU,
+and the batch-sharding path with world_size 2 over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from sketchedit_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CELEB_ARGV = ("--batchSize 1 --nThreads 1 --name celeb --joint_train_inp --dataset_mode testimage "
+              "--image_dirs {d}/images --mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png "
+              "--mask_postfix .png --model editline2 --netG deepfillc2 --pool_type max --use_cam "
+              "--which_epoch latest --output_dir {d}/results")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    _lib.build_library()
+    return ctypes.CDLL(_lib.LIB_PATH)
+
+
+def test_header_symbols_exported(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "sketchedit_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(se_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert getattr(built_lib, s) is not None
+    built_lib.se_version.restype = ctypes.c_char_p
+    assert b"gfx950" in built_lib.se_version()
+
+
+def test_library_contains_gfx950_code():
+    assert b"gfx950" in open(_lib.LIB_PATH, "rb").read()
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SketchEditHipError):
+        _lib.Engine(0)
+
+
+def _opt(tmp_path):
+    from sketchedit_amd.options.test_options import TestOptions
+    return TestOptions().parse(CELEB_ARGV.format(d=tmp_path).split(), quiet=True)
+
+
+def test_options_celeb_command_line(tmp_path):
+    o = _opt(tmp_path)
+    assert (o.model, o.netG, o.pool_type, o.use_cam, o.joint_train_inp) == ("editline2", "deepfillc2", "max", True, True)
+    assert o.gpu_ids == [0] and o.isTrain is False and o.which_epoch == "latest" and o.how_many == float("inf")
+    assert o.no_mask_cc is False and o.no_mask_coarse is False and o.image_postfix == ".png"
+    assert _lib.flags_from_opt(o) == (_lib.FLAG_USE_CAM | _lib.FLAG_POOL_MAX | _lib.FLAG_JOINT_TRAIN_INP)
+    o.pool_type = "bogus"
+    with pytest.raises(NotImplementedError):
+        _lib.flags_from_opt(o)
+
+
+def test_registries_and_state_dict_contract(tmp_path):
+    from sketchedit_amd import models
+    from sketchedit_amd.models import networks
+    o = _opt(tmp_path)
+    assert models.find_model_using_name("editline2").__name__ == "EditLine2Model"
+    G = networks.find_network_using_name("deepfillc2", "generator")
+    M = networks.find_network_using_name("MD", "generator")
+    assert (G.__name__, M.__name__) == ("DeepFillC2Generator", "MDGenerator")
+    g, m = G(o), M(o)
+    # checkpoint contract of the reference: 104 / 48 tensors, 5 366 430 / 2 112 820 parameters
+    assert len(g.state_dict()) == 104 and sum(p.numel() for p in g.parameters()) == 5366430
+    assert len(m.state_dict()) == 48 and sum(p.numel() for p in m.parameters()) == 2112820
+    for net, mod in (("G", g), ("M", m)):
+        sd = synth.make_state_dict(net, 0)
+        assert set(sd) == set(mod.state_dict())
+        for k, v in mod.state_dict().items():
+            assert tuple(v.shape) == sd[k].shape, k
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})      # strict
+    assert g.conv10_atrous.dilation == (16, 16) and g.conv10_atrous.padding == (16, 16)
+    assert g.conv2_downsample.stride == (2, 2) and g.pmconv6.act == "relu" and g.conv17.act is None
+    assert g.conv13_upsample_conv.upsample and m.conv_mask_17.out_channels == 1
+    with pytest.raises(_lib.SketchEditHipError):        # CPU tensors: no fallback
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 1, 64, 64))
+
+
+def test_checkpoint_roundtrip_module_prefix(tmp_path):
+    from sketchedit_amd.models.networks.generator import MDGenerator
+    from sketchedit_amd.util import util
+    o = _opt(tmp_path)
+    o.checkpoints_dir = str(tmp_path / "ckpt")
+    m = MDGenerator(o)
+    sd = {("module." + k): torch.from_numpy(v) for k, v in synth.make_state_dict("M", 3).items()}
+    os.makedirs(os.path.join(o.checkpoints_dir, o.name))
+    torch.save(sd, util.checkpoint_path("M", "latest", o))
+    util.load_network(m, "M", "latest", o)
+    assert torch.equal(m.conv1.weight.detach(), sd["module.conv1.weight"])
+
+
+def test_dataset_contract(tmp_path):
+    from PIL import Image
+    from sketchedit_amd import data
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    rng = np.random.RandomState(0)
+    for i, (w, h) in enumerate([(64, 48), (64, 48)]):
+        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(tmp_path / "images" / ("im%d.png" % i))
+        e = (rng.rand(h // 2, w // 2) < 0.05).astype(np.uint8) * 255      # half size: must be resized to the image
+        Image.fromarray(e).save(tmp_path / "edges" / ("im%d.png" % i))
+    (tmp_path / "list.txt").write_text("im0.png\nim1.png\n")
+    o = _opt(tmp_path)
+    o.nThreads = 0
+    dl = data.create_dataloader(o)
+    batch = next(iter(dl))
+    assert batch["image"].shape == (1, 3, 48, 64) and batch["mask"].shape == (1, 1, 48, 64)
+    assert float(batch["image"].min()) >= -1 and float(batch["image"].max()) <= 1
+    assert set(np.unique(batch["mask"].numpy())) <= {0.0, 1.0} and batch["path"][0] == "im0.png"
+    assert torch.equal(batch["image"], batch["gt"])
+
+
+def test_synth_shard_consistency():
+    full = synth.make_inputs(4, 16, 16, seed=5)
+    part = synth.make_inputs(2, 16, 16, seed=5, first_index=2)
+    assert np.array_equal(full[0][2:], part[0]) and np.array_equal(full[1][2:], part[1])
+
+
+def test_shard_range():
+    from sketchedit_amd.shard import shard_range
+    for n, w in ((32, 8), (10, 4), (3, 2), (256, 8)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from sketchedit_amd import synth
+from sketchedit_amd.shard import sharded_inference
+from oracle import sketchedit_oracle as O
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+torch.set_num_threads(2)
+WM = synth.make_state_dict("M", 0)
+img, sk = synth.make_inputs(2, 32, 32, seed=21)
+img, sk = torch.from_numpy(img), torch.from_numpy(sk)
+def fwd(i, s):   # stand-in for the HIP forward on this rank (CPU box): netM of the oracle
+    with torch.no_grad():
+        m, mi = O.netM_forward(WM, i, s)
+    return mi, m
+comp, mask = sharded_inference(fwd, img, sk)
+if dist.get_rank() == 0:
+    full_c, full_m = fwd(img, sk)
+    assert comp.shape == full_c.shape and mask.shape == full_m.shape
+    assert float((comp - full_c).abs().max()) < 1e-6 and float((mask - full_m).abs().max()) < 1e-6
+    print("SHARD_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_inference_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "SHARD_OK" in outs[0]
