@@ -113,3 +113,31 @@ def test_concurrent_callers(model):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_test_py_script_end_to_end(tmp_path):
+    """The reference's entry point: test.py with a test_celeb.sh-style command line, PNG in -> PNG out."""
+    import importlib.util
+    from PIL import Image
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    rng = np.random.RandomState(0)
+    names = []
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8)).save(tmp_path / "images" / ("f%d.png" % i))
+        Image.fromarray(((rng.rand(64, 64) < 0.01) * 255).astype(np.uint8)).save(tmp_path / "edges" / ("f%d.png" % i))
+        names.append("f%d.png" % i)
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    argv = ("--batchSize 2 --nThreads 0 --name celeb --joint_train_inp --dataset_mode testimage --image_dirs {d}/images "
+            "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
+            "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --output_dir {d}/results "
+            "--output_mask_dir {d}/masks --synthetic_weights").format(d=tmp_path).split()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_test_script", os.path.join(root, "test.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(argv)
+    for n in names:
+        out = np.asarray(Image.open(tmp_path / "results" / n))
+        msk = np.asarray(Image.open(tmp_path / "masks" / n))
+        assert out.shape == (64, 64, 3) and msk.shape == (64, 64)
