@@ -172,3 +172,31 @@ def test_op_attention_all_invalid(golden_dir):
     assert _maxdiff(P, g["op.att_allinvalid.similar"]) < TOL
     assert _maxdiff(out, g["op.att_allinvalid.out"]) < 1e-5
     assert abs(float(P[0, 0, 0, 0]) - 1.0 / P.shape[1]) < 1e-7
+
+
+# ---- the torch-free C restatement (oracle/ref_ops.c) against the same reference-generated vectors ----
+@pytest.mark.parametrize("case", OPS, ids=[c[0] for c in OPS])
+def test_c_oracle_gated_conv(golden_dir, case):
+    from oracle import ref_ops
+    name, cin, cout, k, s, r, act, H, W = case
+    g = _load(golden_dir, "ops.npz")
+    w = synth.uniform(7, name + ".w", (cout, cin, k, k), -0.5, 0.5)
+    b = synth.uniform(7, name + ".b", (cout,), -0.5, 0.5)
+    x = synth.uniform(7, name + ".x", (2, cin, H, W), -1, 1)
+    assert _maxdiff(ref_ops.gated_conv(x, w, b, s, r, act), g["op." + name]) < 5e-6   # double vs fp32 accumulation
+
+
+def test_c_oracle_deconv_and_attention(golden_dir):
+    from oracle import ref_ops
+    g = _load(golden_dir, "ops.npz")
+    w = synth.uniform(7, "deconv.w", (16, 8, 3, 3), -0.5, 0.5)
+    b = synth.uniform(7, "deconv.b", (16,), -0.5, 0.5)
+    x = synth.uniform(7, "deconv.x", (2, 8, 6, 8), -1, 1)
+    assert _maxdiff(ref_ops.gated_conv(x, w, b, upsample=True), g["op.deconv"]) < TOL
+    xa, full = att_inputs()
+    out, sim = ref_ops.attention(xa.numpy(), full.numpy())
+    assert _maxdiff(sim, g["op.att.similar"]) < TOL
+    assert _maxdiff(out, g["op.att.out"]) < 1e-5
+    out, sim = ref_ops.attention(xa.numpy(), np.ones((2, 1, 48, 64), np.float32))
+    assert _maxdiff(sim, g["op.att_allinvalid.similar"]) < TOL
+    assert _maxdiff(out, g["op.att_allinvalid.out"]) < 1e-5
