@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="add the per-layer timing table to the JSON line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,7 +139,8 @@ def main():
         nprof = 2
         for _ in range(nprof):
             eng.inference(img, sk, FLAGS, out=out)
-        rep = eng.profile_report()
+        full_rep = eng.profile_report()
+        rep = full_rep["kernels"]
         eng.profile(False)
         kernels = {r["kernel"]: {"launches_per_step": r["launches"] // nprof,
                                  "ms_per_step": r["total_ms"] / nprof,
@@ -186,6 +188,9 @@ def main():
                        "global_batch": world * B, "size": S, "per_gpu_batch": B,
                        "collective": "all_gather(composed, mask)" if world > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
+            "layers": ({r["layer"]: {"ms": round(r["total_ms"] / nprof, 4), "n": r["launches"] // nprof,
+                                     "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)}
+                        for r in full_rep["layers"]} if args.layers else None),
             "forward_tflops_live": (LIVE_GFLOP_PER_IMAGE.get(S, 0) * images / elapsed / 1e3) or None,
         }
         print(json.dumps(line))

@@ -246,7 +246,7 @@ class Engine:
 
     def profile_report(self):
         import json
-        buf = ctypes.create_string_buffer(1 << 16)
+        buf = ctypes.create_string_buffer(1 << 18)
         if self.lib.se_profile_report(self.h, buf, len(buf)):
             self._err("se_profile_report")
         return json.loads(buf.value.decode())

@@ -182,23 +182,40 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   if (cfg < 0 || (G % 4)) return fail(c, "layer %s: unsupported gated width %d", d.name, G);
   const int NP = gconv_np(cfg);
   const int Cp = (int)cin_map.size();          // packed channels per tap (multiple of 4)
-  const int T = d.k * d.k;
+  // gen_deconv (nearest x2 + 3x3) is packed in its sub-pixel form: 4 output parity classes, each a 2x2 conv on
+  // the source grid; tap a of class py sums the kernel rows that land on source row yy + a - 1 + py:
+  //   py=0: a=0 <- {ky 0}, a=1 <- {ky 1,2};   py=1: a=0 <- {ky 0,1}, a=1 <- {ky 2}      (same for columns)
+  const bool up2 = d.up != 0;
+  const int KW = up2 ? 2 : d.k;
+  const int T = KW * KW;
   const int K = T * Cp;
   const int nch = (K + 31) / 32;
-  std::vector<float> img((size_t)nch * NP * 32, 0.f), bias(NP, 0.f);
-  for (int n = 0; n < NP; ++n) {
-    const int oc = out_channel_of_row(cfg, n, G, d.cout);
-    if (oc < 0) continue;
-    bias[n] = L.b[oc];
-    for (int kf = 0; kf < K; ++kf) {
-      const int tap = kf / Cp, pc = kf % Cp;
-      const int ic = cin_map[pc];
-      if (ic < 0) continue;
-      const int ky = tap / d.k, kx = tap % d.k;
-      const float v = L.w[(((size_t)oc * d.cin + ic) * d.k + ky) * d.k + kx];
-      const int ch = kf / 32, kin = kf % 32, s = kin / 4, e = kin % 4;
-      const int ps = s ^ ((n >> 1) & 7);
-      img[((size_t)ch * NP + n) * 32 + ps * 4 + e] = v;
+  const int ncls = up2 ? 4 : 1;
+  std::vector<float> img((size_t)ncls * nch * NP * 32, 0.f), bias(NP, 0.f);
+  auto lo = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2); };
+  auto hi = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2); };
+  for (int cls = 0; cls < ncls; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    for (int n = 0; n < NP; ++n) {
+      const int oc = out_channel_of_row(cfg, n, G, d.cout);
+      if (oc < 0) continue;
+      bias[n] = L.b[oc];
+      for (int kf = 0; kf < K; ++kf) {
+        const int tap = kf / Cp, pc = kf % Cp;
+        const int ic = cin_map[pc];
+        if (ic < 0) continue;
+        const int ty = tap / KW, tx = tap % KW;
+        float v = 0.f;
+        if (up2) {
+          for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
+            for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx) v += L.w[(((size_t)oc * d.cin + ic) * 3 + ky) * 3 + kx];
+        } else {
+          v = L.w[(((size_t)oc * d.cin + ic) * d.k + ty) * d.k + tx];
+        }
+        const int ch = kf / 32, kin = kf % 32, s = kin / 4, e = kin % 4;
+        const int ps = s ^ ((n >> 1) & 7);
+        img[(((size_t)cls * nch + ch) * NP + n) * 32 + ps * 4 + e] = v;
+      }
     }
   }
   if (L.d_w) (void)hipFree(L.d_w);
@@ -261,22 +278,24 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   GConvParams p;
   memset(&p, 0, sizeof p);
   p.src0 = src0; p.src1 = src1 ? src1 : src0; p.wpk = L.d_w; p.bias = L.d_b; p.dst = dst; p.zeros = c->zeros;
-  p.B = B; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Ho = d.up ? Hin : Ho; p.Wo = d.up ? Win : Wo;   // up2: rows walk the source grid
+  p.up2 = d.up ? 1 : 0; p.OH = Ho; p.OW = Wo;
   p.C0 = C0; p.C1 = C1 ? C1 : C0; p.C0g = C0 / 4; p.CG = L.CGp;
-  p.T = L.T; p.KW = d.k; p.stride = d.stride; p.dil = d.rate; p.pad = pad;
-  p.magicCG = (65536 + L.CGp - 1) / L.CGp; p.magicKW = 256 / d.k + 1;
+  const int KW = d.up ? 2 : d.k;
+  p.T = L.T; p.KW = KW; p.stride = d.stride; p.dil = d.rate; p.pad = pad;
+  p.magicCG = (65536 + L.CGp - 1) / L.CGp; p.magicKW = 256 / KW + 1;
   for (int gi = 0; gi < L.nch * 8 + 8; ++gi)
     if (((gi * p.magicCG) >> 16) != gi / L.CGp) return fail(c, "layer %s: magic division check failed", d.name);
   for (int t = 0; t <= L.T + 8; ++t)
-    if (((t * p.magicKW) >> 8) != t / d.k) return fail(c, "layer %s: magic tap division check failed", d.name);
+    if (((t * p.magicKW) >> 8) != t / KW) return fail(c, "layer %s: magic tap division check failed", d.name);
   if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) >= 2147483648.0 || (double)B * Ho * Wo * L.G >= 2147483648.0)
     return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
-  p.ushift = d.up ? 1 : 0;
-  p.Hlim = d.up ? 2 * Hin : Hin; p.Wlim = d.up ? 2 * Win : Win;
-  p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * Ho * Wo;
+  p.ushift = 0;
+  p.Hlim = Hin; p.Wlim = Win;
+  p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * p.Ho * p.Wo;
   // algorithmic cost as the reference defines the layer (3x3 on the upsampled grid for gen_deconv)
   set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k,
-                  4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)));
+                  4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name);
   HIPCHK(c, launch_gconv(L.cfg, p, c->st));
   return 0;
 }
@@ -357,7 +376,7 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
     sp.mode = mode; sp.out_nchw = out_nchw; sp.hard = hard; sp.img = img; sp.mask = mask; sp.xnow = xnow;
     sp.composed = composed; sp.no_mask_coarse = no_mask_coarse;
     set_launch_cost(2.0 * (double)P.B * in.H * in.W * L.def.cout * 108.0,
-                    4.0 * (double)P.B * in.H * in.W * (12 + L.def.cout));
+                    4.0 * (double)P.B * in.H * in.W * (12 + L.def.cout), L.def.name);
     hipError_t e = launch_small_conv(sp, c->st);
     if (e != hipSuccess) return P.rc = fail(c, "small conv %s: %s", name, hipGetErrorString(e));
   }
@@ -644,7 +663,7 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.label] += t; fl[r.label] += r.flops; by[r.label] += r.bytes; n[r.label]++; }
   }
-  std::string s = "[";
+  std::string s = "{\"kernels\": [";
   bool first = true;
   for (int l = 0; l < PL_COUNT; ++l) {
     if (!n[l]) continue;
@@ -654,7 +673,28 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
     s += t;
     first = false;
   }
-  s += "]";
+  s += "], \"layers\": [";
+  // per (kernel, layer name) in first-seen order
+  std::vector<std::string> keys;
+  std::map<std::string, std::pair<double, double>> agg;   // ms, flops
+  std::map<std::string, long> cnt;
+  for (auto& r : c->prof.recs) {
+    if (!r.name) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    std::string k = std::string(prof_label_name(r.label)) + ":" + r.name;
+    if (!cnt.count(k)) keys.push_back(k);
+    agg[k].first += t; agg[k].second += r.flops; cnt[k]++;
+  }
+  first = true;
+  for (auto& k : keys) {
+    char t[256];
+    snprintf(t, sizeof t, "%s{\"layer\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e}", first ? "" : ", ",
+             k.c_str(), cnt[k], agg[k].first, agg[k].second);
+    s += t;
+    first = false;
+  }
+  s += "]}";
   if (s.size() + 1 > cap) return fail(c, "profile buffer too small");
   memcpy(buf, s.c_str(), s.size() + 1);
   return 0;

@@ -33,8 +33,14 @@ DEVFN unsigned lds_addr_of(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-DEVFN float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // nn.ELU(), alpha 1
+DEVFN float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // nn.ELU(), alpha 1 (accurate form)
 DEVFN float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// epilogue forms on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1-2 ulp): absolute error ~1e-7,
+// three orders below the 1e-3 parity budget
+DEVFN float fast_exp(float x) { return __expf(x); }
+DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEVFN float elu_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
+DEVFN float sigmoid_fast(float x) { return fast_rcp(1.f + fast_exp(-x)); }
 
 // ---- MFMA core ------------------------------------------------------------------------------------
 // One 32-k chunk for a wave tile of NT (rows: packed channels) x PT (cols: pixels) 16x16 tiles.

@@ -15,10 +15,12 @@
 //   concat      models/networks/editline_g.py:166-167,211 (second source = other tensor / pooled vector)
 #include "se_device.h"
 
+#include <cstdlib>
+
 namespace se {
 
-template <int NT, int PT, bool MIXED>
-__global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
+template <int NT, int PT, bool MIXED, int WPS>
+__global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   constexpr int PIX = PT * 64;
   constexpr int NP = NT * 16;
   constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
@@ -26,11 +28,16 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   char* Wb = smem + 2 * XBYTES;
-  int2* rowtab = (int2*)(smem + 2 * XBYTES + 2 * WBYTES);
+  int2* rowtab = (int2*)smem;   // aliases the X buffers: consumed into registers before the first DMA
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile_base = blockIdx.x * PIX;
+  // sub-pixel upsample form: this workgroup computes output pixels (2yy+py, 2xx+px); taps (a,b) in {0,1}^2 read
+  // source (yy + a - 1 + py, xx + b - 1 + px) with weights summed over the 3x3 taps that collapse onto it
+  const int py = p.up2 ? (int)(blockIdx.y >> 1) : 0, px = p.up2 ? (int)(blockIdx.y & 1) : 0;
+  const int pady = p.up2 ? 1 - py : p.pad, padx = p.up2 ? 1 - px : p.pad;
+  const float* wbase = p.wpk + (p.up2 ? (size_t)blockIdx.y * p.nch * NP * 32 : 0);
 
   // ---- row table: (batch, packed y0|x0) of every pixel row of the tile; invalid rows fail the bounds test
   const int HoWo = p.Ho * p.Wo;
@@ -52,6 +59,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     rb[i] = e.x;
     ryx[i] = e.y;
   }
+  __syncthreads();
 
   // staging role of this lane: physical slot ps of rows (piece*8 + lane>>3) <-> logical k-slot s_log
   const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     const int gi = ch * 8 + s_log;
     const int tap = (gi * p.magicCG) >> 16, cg = gi - tap * p.CG;
     const int ky = (tap * p.magicKW) >> 8, kx = tap - ky * p.KW;
-    const int dy = ky * p.dil - p.pad, dx = kx * p.dil - p.pad;
+    const int dy = ky * p.dil - pady, dx = kx * p.dil - padx;
     const bool tapok = tap < p.T;
     const bool first = cg < p.C0g;
     const float* base = first ? p.src0 : p.src1;
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
       glds16(g, xdst + (i * 4 + w) * 1024);
     }
     const unsigned wdst = lds_w + buf * WBYTES;
-    const float* wsrc = p.wpk + (size_t)ch * NP * 32 + lane * 4;
+    const float* wsrc = wbase + (size_t)ch * NP * 32 + lane * 4;
 #pragma unroll
     for (int j = 0; j < (NT * 2 + 3) / 4; ++j) {
       const int rbk = j * 4 + w;
@@ -111,6 +119,12 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
 
   // ---- epilogue: bias, gate, NHWC store (a lane holds 4 consecutive channels of pixel lane&15)
   const int q = lane >> 4;
+  auto out_off = [&](int pidx) -> size_t {
+    if (!p.up2) return (size_t)pidx * p.G;
+    const int b = pidx / HoWo, rem = pidx - b * HoWo;
+    const int yy = rem / p.Wo, xx = rem - yy * p.Wo;
+    return ((size_t)(b * p.OH + 2 * yy + py) * p.OW + 2 * xx + px) * p.G;
+  };
   if (!MIXED) {
     constexpr int NF = NT / 2;       // tiles [0,NF): features, [NF,NT): matching gates
 #pragma unroll
@@ -126,10 +140,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
         for (int r = 0; r < 4; ++r) {
           const float f = acc[nt][pt][r] + bf[r];
           const float g = acc[nt + NF][pt][r] + bg[r];
-          const float a = p.act == 0 ? elu1(f) : fmaxf(f, 0.f);
-          o[r] = a * sigmoidf_(g);
+          const float a = p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f);
+          o[r] = a * sigmoid_fast(g);
         }
-        if (c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + (size_t)pidx * p.G + c0) = o;
+        if (c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + out_off(pidx) + c0) = o;
       }
     }
   } else {
@@ -144,40 +158,70 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          // feature lanes (q<2) and gate lanes (q>=2) share ONE exp: e = exp(v) for features (ELU's negative
+          // side), e = exp(-v) for gates (sigmoid); the gate lanes then ship sigmoid to their feature lane.
           const float v = acc[nt][pt][r] + bq[r];
-          const float g = __shfl_xor(v, 32);        // lanes 0-31 receive their gate pre-activation
-          const float a = p.act == 0 ? elu1(v) : fmaxf(v, 0.f);
-          o[r] = a * sigmoidf_(g);
+          const float e = fast_exp(q < 2 ? v : -v);
+          const float a = p.act == 0 ? (v > 0.f ? v : e - 1.f) : fmaxf(v, 0.f);
+          const float t = q < 2 ? a : fast_rcp(1.f + e);
+          o[r] = t * __shfl_xor(t, 32);
         }
-        if (q < 2 && c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + (size_t)pidx * p.G + c0) = o;
+        if (q < 2 && c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + out_off(pidx) + c0) = o;
       }
     }
   }
 }
 
-template <int NT, int PT, bool MIXED>
-static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st) {
+template <int NT, int PT, bool MIXED, int WPS>
+static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label) {
   constexpr int PIX = PT * 64;
-  constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128 + PIX * 8;
+  constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128;
+  static_assert(PIX * 8 <= 2 * PIX * 128, "row table aliases the X buffers");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gconv_kernel<NT, PT, MIXED>,
+    hipError_t e = hipFuncSetAttribute((const void*)gconv_kernel<NT, PT, MIXED, WPS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int grid = (p.total_pix + PIX - 1) / PIX;
-  ProfScope ps_(st, NT == 12 ? PL_GCONV_N192 : NT == 6 ? PL_GCONV_N96 : NT == 3 ? PL_GCONV_N48 : PL_GCONV_N24);
-  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED>), dim3(grid), dim3(256), LDS, st, p);
+  ProfScope ps_(st, label);
+  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS>), dim3(grid, p.up2 ? 4 : 1), dim3(256), LDS, st, p);
   return hipGetLastError();
 }
 
+// Tile shapes.  variant 0 is the default; SE_GCONV_VARIANT_<cfg>=k (environment) selects another one for
+// tuning sweeps.  Shapes with LDS <= 80 KiB and <= 256 registers run two workgroups per CU, so the staging
+// code, LDS-read latency and epilogue of one overlap the MFMAs of the other.
+static int variant_of(int cfg) {
+  static int v[4] = {-1, -1, -1, -1};
+  if (v[cfg] < 0) {
+    static const char* names[4] = {"SE_GCONV_VARIANT_N192", "SE_GCONV_VARIANT_N96", "SE_GCONV_VARIANT_N48",
+                                   "SE_GCONV_VARIANT_N24"};
+    const char* e = getenv(names[cfg]);
+    v[cfg] = e ? atoi(e) : 0;
+  }
+  return v[cfg];
+}
+
 hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
+  const int var = variant_of(cfg);
   switch (cfg) {
-    case GC_N192: return launch_gconv_t<12, 4, false>(p, st);
-    case GC_N96: return launch_gconv_t<6, 4, false>(p, st);
-    case GC_N48: return launch_gconv_t<3, 8, true>(p, st);
-    case GC_N24: return launch_gconv_t<2, 8, true>(p, st);
+    case GC_N192:
+      if (var == 1) return launch_gconv_t<12, 4, false, 1>(p, st, PL_GCONV_N192);
+      return launch_gconv_t<12, 2, false, 2>(p, st, PL_GCONV_N192);
+    case GC_N96:
+      if (var == 1) return launch_gconv_t<6, 4, false, 1>(p, st, PL_GCONV_N96);
+      if (var == 2) return launch_gconv_t<6, 2, false, 2>(p, st, PL_GCONV_N96);
+      return launch_gconv_t<6, 3, false, 2>(p, st, PL_GCONV_N96);
+    case GC_N48:
+      if (var == 1) return launch_gconv_t<3, 8, true, 1>(p, st, PL_GCONV_N48);
+      if (var == 2) return launch_gconv_t<3, 4, true, 2>(p, st, PL_GCONV_N48);
+      return launch_gconv_t<3, 2, true, 2>(p, st, PL_GCONV_N48);
+    case GC_N24:
+      if (var == 1) return launch_gconv_t<2, 8, true, 1>(p, st, PL_GCONV_N24);
+      if (var == 2) return launch_gconv_t<2, 4, true, 2>(p, st, PL_GCONV_N24);
+      return launch_gconv_t<2, 2, true, 2>(p, st, PL_GCONV_N24);
   }
   return hipErrorInvalidValue;
 }

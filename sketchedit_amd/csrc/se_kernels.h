@@ -17,12 +17,12 @@ enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL
                  PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
 const char* prof_label_name(int l);
 struct Profiler {
-  struct Rec { int label; double flops; double bytes; hipEvent_t a, b; };
+  struct Rec { int label; const char* name; double flops; double bytes; hipEvent_t a, b; };
   std::vector<Rec> recs;
   bool on = false;
 };
 void set_profiler(Profiler* p);          // thread-local; set by the API under the ctx lock
-void set_launch_cost(double flops, double bytes);   // algorithmic cost of the NEXT launch (consumed once)
+void set_launch_cost(double flops, double bytes, const char* name = nullptr);   // cost/name of the NEXT launch (consumed once)
 
 // ---------------------------------------------------------------------------------------------
 // Gather-GEMM gated convolution (the hot kernel).
@@ -44,6 +44,9 @@ struct GConvParams {
   int magicCG, magicKW; // x/CG == (x*magicCG)>>16, t/KW == (t*magicKW)>>8 on the ranges used (host-verified)
   int stride, dil, pad;
   int ushift;          // 1: source is read through a nearest x2 upsample (coords >> 1)
+  int up2;             // 1: sub-pixel form of nearest-x2 + 3x3: blockIdx.y = output parity class (py,px), a 2x2 conv
+                       //    on the source grid with pre-summed weights; (Ho,Wo) is then the SOURCE grid, (OH,OW) the output
+  int OH, OW;
   int Hlim, Wlim;      // validity limits of the pre-shift tap coordinates
   int src1_vec;        // src1 is a per-batch vector (spatially constant, still zero padded)
   int nch;             // number of 32-k chunks

@@ -9,8 +9,9 @@ namespace se {
 // ---- profiler plumbing ----------------------------------------------------------------------------
 static thread_local Profiler* g_prof = nullptr;
 static thread_local double g_next_flops = 0.0, g_next_bytes = 0.0;
+static thread_local const char* g_next_name = nullptr;
 void set_profiler(Profiler* p) { g_prof = p; }
-void set_launch_cost(double flops, double bytes) { g_next_flops = flops; g_next_bytes = bytes; }
+void set_launch_cost(double flops, double bytes, const char* name) { g_next_flops = flops; g_next_bytes = bytes; g_next_name = name; }
 const char* prof_label_name(int l) {
   static const char* n[PL_COUNT] = {"gconv_n192", "gconv_n96", "gconv_n48", "gconv_n24", "small_conv", "pack",
                                     "colreduce", "att_prep", "att_score", "att_softmax", "att_pv", "layout"};
@@ -20,10 +21,12 @@ const char* prof_label_name(int l) {
 ProfScope::ProfScope(hipStream_t s, int label) : st(s) {
   Profiler* p = g_prof;
   const double fl = g_next_flops, by = g_next_bytes;
+  const char* nm = g_next_name;
   g_next_flops = g_next_bytes = 0.0;
+  g_next_name = nullptr;
   if (!p || !p->on) return;
   Profiler::Rec r;
-  r.label = label; r.flops = fl; r.bytes = by;
+  r.label = label; r.name = nm; r.flops = fl; r.bytes = by;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   (void)hipEventRecord(r.a, st);
   p->recs.push_back(r);
