@@ -231,3 +231,38 @@ def test_errors(eng_w):
         eng_w.load_state_dict("G", {"nonexistent.weight": np.zeros((1, 1, 3, 3), np.float32)})
     with pytest.raises(SketchEditHipError):
         eng_w.load_state_dict("G", {"conv1.weight": np.zeros((48, 4, 5, 5), np.float32)})
+
+
+def test_512_parity_vs_oracle(eng_w):
+    """BASELINE config 3 resolution (512x512, L = 3969 attention keys): one image against the oracle."""
+    from oracle import sketchedit_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    img, sk = synth.make_inputs(1, 512, 512, seed=1234)
+    WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
+    ref = O.inference(WM, WG, img, sk)
+    r = eng_w.inference(_cuda(img), _cuda(sk), FLAGS, visualize=True)
+    assert 0.1 < float(ref["hard_mask"].mean()) < 0.9
+    assert _md(r["mask"], ref["mask"]) < TOL_E2E
+    flips = int((r["hard"].cpu() != ref["hard_mask"]).sum())
+    # netG given the oracle's hard mask (independent of threshold flips)
+    hard = ref["hard_mask"].cuda()
+    ci, cs = _cuda(img), _cuda(sk)
+    coarse, fine = eng_w.netG(ci, ci, hard, hard, cs, FLAGS)
+    assert _md(coarse, ref["coarse"]) < TOL_E2E
+    assert _md(fine, ref["fine"]) < TOL_E2E
+    if flips == 0:
+        assert _md(r["composed"], ref["composed"]) < TOL_E2E
+    assert flips <= 2, "hard-mask flips at 512x512: %d" % flips
+
+
+def test_512_batch8_properties(eng_w):
+    """BASELINE config 3 size (512x512, B=8): finite, composite identity, shard invariance."""
+    img, sk = synth.make_inputs(8, 512, 512, seed=99)
+    ci, cs = _cuda(img), _cuda(sk)
+    r = eng_w.inference(ci, cs, FLAGS, visualize=True)
+    for k in ("composed", "mask", "fine", "coarse"):
+        assert torch.isfinite(r[k]).all(), k
+    comp = r["fine"] * r["mask"] + ci * (1 - r["mask"])
+    assert float((comp - r["composed"]).abs().max()) < 1e-6
+    one = eng_w.inference(ci[3:4].contiguous(), cs[3:4].contiguous(), FLAGS)
+    assert torch.equal(one["composed"], r["composed"][3:4])
