@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsketchedit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["se_gconv.hip", "se_attention.hip", "se_misc.hip", "se_api.hip"]
+SOURCES = ["se_gconv.hip", "se_wino.hip", "se_attention.hip", "se_misc.hip", "se_api.hip"]
 
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16

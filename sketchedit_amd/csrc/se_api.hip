@@ -10,6 +10,7 @@
 #include "se_kernels.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -69,6 +70,7 @@ struct Layer {
   int cfg = -1, NP = 0, nch = 0, G = 0, CGp = 0, T = 0, C0 = 0, C1 = 0;
   float* d_w = nullptr;
   float* d_b = nullptr;
+  float* d_u = nullptr;       // Winograd-transformed weights (eligible layers only)
 };
 
 // ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
@@ -151,6 +153,9 @@ int fail(se_ctx* c, const char* fmt, ...) {
 // Build the LDS image [nch][NP][32] of a gated conv: row n = packed output channel, k = flattened
 // (tap, packed input channel); the 16-B slot s of row n is stored at physical slot s ^ ((n>>1)&7).
 // cin_map[pc] = checkpoint input channel of packed channel pc, or -1 for zero padding.
+bool wino_eligible_layer(const LayerDef& d);
+int pack_wino(se_ctx* c, Layer& L);
+
 int choose_cfg(int G) {
   if (G <= 16) return GC_N24;
   if (G <= 24) return GC_N48;
@@ -226,6 +231,39 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   HIPCHK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   L.cfg = cfg; L.NP = NP; L.nch = nch; L.G = G; L.CGp = Cp / 4; L.T = T;
   L.packed = true;
+  if (wino_eligible_layer(d) && Cp == 96) return pack_wino(c, L);
+  return 0;
+}
+
+// Winograd F(2x2,3x3) weights: U[pos] = (G g G^T)[xi][nu] per (out, in) pair, packed per position like a 1x1
+// conv 96 -> 192 in the N=192 row order (features then gates) with the same slot swizzle.
+bool wino_eligible_layer(const LayerDef& d) {
+  return d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && d.act != ACT_NONE;
+}
+int pack_wino(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int NP = 192, nch = 3;
+  std::vector<float> img((size_t)16 * nch * NP * 32, 0.f);
+  for (int n = 0; n < NP; ++n) {
+    const int oc = out_channel_of_row(GC_N192, n, 96, 192);
+    for (int ic = 0; ic < 96; ++ic) {
+      const float* g = &L.w[((size_t)oc * 96 + ic) * 9];
+      float t[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int kx = 0; kx < 3; ++kx) t[i][kx] = Gm[i][0] * g[kx] + Gm[i][1] * g[3 + kx] + Gm[i][2] * g[6 + kx];
+      for (int xi = 0; xi < 4; ++xi)
+        for (int nu = 0; nu < 4; ++nu) {
+          const float u = t[xi][0] * Gm[nu][0] + t[xi][1] * Gm[nu][1] + t[xi][2] * Gm[nu][2];
+          const int pos = xi * 4 + nu, ch = ic / 32, kin = ic % 32, s_ = kin / 4, e = kin % 4;
+          const int ps = s_ ^ ((n >> 1) & 7);
+          img[(((size_t)pos * nch + ch) * NP + n) * 32 + ps * 4 + e] = u;
+        }
+    }
+  }
+  if (L.d_u) (void)hipFree(L.d_u);
+  HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -275,6 +313,18 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   if (c->dry) return 0;
   if (!L.packed) return fail(c, "layer %s: weights not loaded", d.name);
   if ((C0 + C1) != L.CGp * 4) return fail(c, "layer %s: source channels %d+%d != packed %d", d.name, C0, C1, L.CGp * 4);
+  static const bool use_wino = !(getenv("SE_WINOGRAD") && atoi(getenv("SE_WINOGRAD")) == 0);
+  if (use_wino && L.d_u && !src1 && C0 == 96 && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+    WinoParams wp;
+    memset(&wp, 0, sizeof wp);
+    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_b; wp.dst = dst; wp.zeros = c->zeros;
+    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
+    wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+    if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
+    set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name);
+    HIPCHK(c, launch_wino(wp, c->st));
+    return 0;
+  }
   GConvParams p;
   memset(&p, 0, sizeof p);
   p.src0 = src0; p.src1 = src1 ? src1 : src0; p.wpk = L.d_w; p.bias = L.d_b; p.dst = dst; p.zeros = c->zeros;
@@ -529,6 +579,7 @@ void se_destroy(se_ctx* c) {
     for (auto& kv : *net) {
       if (kv.second.d_w) (void)hipFree(kv.second.d_w);
       if (kv.second.d_b) (void)hipFree(kv.second.d_b);
+      if (kv.second.d_u) (void)hipFree(kv.second.d_u);
     }
   if (c->zeros) (void)hipFree(c->zeros);
   delete c;
@@ -745,6 +796,7 @@ int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host
   if (yout) (void)hipFree(yout);
   if (L.d_w) (void)hipFree(L.d_w);
   if (L.d_b) (void)hipFree(L.d_b);
+  if (L.d_u) (void)hipFree(L.d_u);
   return rc;
 }
 

@@ -13,7 +13,7 @@ namespace se {
 // Optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline
 // figures.  Off by default; when off the launch wrappers add nothing.
 // ---------------------------------------------------------------------------------------------
-enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL_SMALL_CONV, PL_PACK, PL_COLREDUCE,
+enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL_WINO_N192, PL_SMALL_CONV, PL_PACK, PL_COLREDUCE,
                  PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
 const char* prof_label_name(int l);
 struct Profiler {
@@ -61,6 +61,22 @@ static inline int gconv_np(int cfg) { return cfg == GC_N192 ? 192 : cfg == GC_N9
 static inline bool gconv_mixed(int cfg) { return cfg >= GC_N48; }
 
 hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) form of the 3x3 stride-1 gated conv 96 -> 192 (se_wino.hip)
+// ---------------------------------------------------------------------------------------------
+struct WinoParams {
+  const float* src;    // NHWC [B][h][w][96]
+  const float* upk;    // [16 positions][3 chunks][192 packed rows][32]: G g G^T, LDS image (pre-swizzled)
+  const float* bias;   // [192] packed-row order (features, then gates)
+  float* dst;          // NHWC [B][h][w][96]
+  const float* zeros;
+  int B, h, w, d;      // dilation d; h % 2d == 0 and w % 2d == 0
+  int th, tw;          // tile grid h/2 x w/2
+  int total_tiles;     // B*th*tw
+  int act;             // 0 ELU, 1 ReLU
+};
+hipError_t launch_wino(const WinoParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 conv 12 -> {1,3} raw output + fused tanh/sigmoid/composite (final layer of each decoder)

@@ -100,6 +100,25 @@ def test_op_gated_conv_network_shapes(eng, shape):
     assert _md(y, ref) < TOL_OP
 
 
+WINO = [(1, 16, 16, "elu"), (2, 16, 24, "elu"), (4, 16, 32, "elu"), (8, 32, 16, "relu"), (16, 64, 32, "elu"),
+        (1, 10, 14, "elu")]
+
+
+@pytest.mark.parametrize("case", WINO, ids=["d%d-%dx%d-%s" % c for c in WINO])
+def test_op_winograd_path_vs_oracle(eng, case):
+    """96 -> 192 3x3 stride 1: sizes with h % 2d == w % 2d == 0 take the Winograd F(2x2,3x3) kernel
+    (se_wino.hip), the last (10x14 ... but d=1 -> eligible too) covers a ragged tile count."""
+    from oracle import sketchedit_oracle as O
+    d, H, W, act = case
+    a = 1.5 / np.sqrt(96 * 9)
+    w = synth.uniform(13, "wino.w%s" % (case,), (192, 96, 3, 3), -a, a)
+    b = synth.uniform(13, "wino.b%s" % (case,), (192,), -0.3, 0.3)
+    x = synth.uniform(13, "wino.x%s" % (case,), (3, 96, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act)
+    assert _md(y, ref) < TOL_OP
+
+
 def test_op_attention_vs_oracle(eng):
     from oracle import sketchedit_oracle as O
     x = synth.uniform(5, "att96.x", (2, 96, 12, 16), -1, 1)
