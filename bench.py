@@ -149,8 +149,8 @@ def main():
                    for r in rep}
         dom = max(rep, key=lambda r: r["total_ms"])
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        conv_ms = sum(r["total_ms"] for r in rep if r["kernel"].startswith("gconv")) / nprof
-        conv_fl = sum(r["flops"] for r in rep if r["kernel"].startswith("gconv")) / nprof
+        conv_ms = sum(r["total_ms"] for r in rep if r["kernel"].startswith(("gconv", "wino"))) / nprof
+        conv_fl = sum(r["flops"] for r in rep if r["kernel"].startswith(("gconv", "wino"))) / nprof
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 3),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None,

@@ -10,20 +10,31 @@
 // sub-images, so a tile's 4x4 inputs are (y0 + (i-1)d, x0 + (j-1)d) and its outputs (y0 + a d, x0 + b d).
 //
 // One workgroup = 8 waves (two per SIMD) = 64 tiles x all 192 packed channels; wave w owns 16 tiles (MFMA columns)
-// and one half of the channels (3 feature tiles + their 3 gate tiles).  Loop over (position, 32-k chunk):
-//   * X tile [64 tiles][32 k]: each lane builds ONE granule = B^T x B at this position from 4 input granules
-//     (global loads, issued one iteration ahead) and writes it to LDS -- the input transform is fused, no
-//     transformed tensor ever exists in HBM;
+// and one half of the channels (3 feature tiles + their 3 gate tiles, so the gate is a register epilogue).
+// Loop over it = (position, 32-k chunk), 48 iterations, double-buffered LDS, one barrier per iteration:
+//   * X tile [64 tiles][32 k]: each lane builds ONE granule = (B^T x B) at this position from 4 raw input granules
+//     (global loads issued at the start of the previous iteration) and writes it to LDS -- the input transform is
+//     fused, no transformed tensor ever exists in HBM;
 //   * W tile [192][32 k] of the host-transformed weights G g G^T by LDS-DMA;
-//   * MFMA into the position accumulator; after the last chunk of a position the accumulator is folded into the
-//     four output accumulators with the A^T coefficients (inverse transform in registers);
-// epilogue: bias, ELU/ReLU * sigmoid gate, NHWC store.  Zero padding = zero-filled input granules.
+//   * 48 MFMAs per wave into the position accumulator; after the last chunk of a position it is folded into the
+//     four output accumulators with the A^T coefficients (inverse transform in registers).
+// Schedule (from s_memtime stamps: of ~4.1k cycles per iteration only 3.1k are MFMA pipe time; ~1.0-1.6k was spent
+// waiting for the pipe to drain before the inverse adds and ~250 issuing the DMA): the fold of position P runs in
+// the MFMA shadow of the NEXT iteration (the accumulator is double-buffered), and the DMA / global-load issue for
+// iteration it+1 sits between the two MFMA halves, fenced with sched_barrier so hipcc keeps it there.
+// Other layouts tried and measured slower on this kernel (kept out of the tree): raw granules resident in
+// registers with a 3-deep W ring (spills at 256 VGPRs), 16-wave workgroups with 3 channel tiles per wave and an
+// LDS gate exchange (spills at 128 VGPRs), two 4-wave workgroups per CU (344 VGPRs needed).
 #include "se_device.h"
+
+#include <cstdlib>
 
 namespace se {
 
-__global__ __launch_bounds__(512) void wino_kernel(const WinoParams p) {
-  constexpr int XB = 64 * 128, WB = 192 * 128;
+__global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
+  constexpr int TILES = 64;
+  constexpr int XB = TILES * 128, WB = 192 * 128;
+  constexpr int NIT = 48;              // 16 positions x 3 chunks
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   char* Wb = smem + 2 * XB;
@@ -31,7 +42,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chh = w & 1, tg = w >> 1;          // channel half, tile group
-  const int tile_base = blockIdx.x * 64;
+  const int tile_base = blockIdx.x * TILES;
   const int tpi = p.th * p.tw;                 // tiles per image
 
   // tile -> (batch, first output pixel).  iy walks the tile grid; y0 = 2d*(iy/d) + iy%d
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoParams p) {
       xo[i] = ((unsigned)x < (unsigned)p.w) ? x : -1;
     }
   }
-  const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
+  const unsigned lds_w = lds_addr_of(Wb);
   int off0, off1;
   frag_offsets(lane, off0, off1);
 
@@ -69,21 +80,21 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoParams p) {
     const int ya = xi == 0 ? yo[0] : yo[1], yb = xi == 3 ? yo[3] : yo[2];
     const int xa = nu == 0 ? xo[0] : xo[1], xb = nu == 3 ? xo[3] : xo[2];
     const int coff = (chunk * 8 + s_log) * 4;
-    const float* g00 = (ya >= 0 && xa >= 0) ? p.src + ((size_t)(unsigned)(ya + xa) * 96 + coff) : p.zeros;
-    const float* g01 = (ya >= 0 && xb >= 0) ? p.src + ((size_t)(unsigned)(ya + xb) * 96 + coff) : p.zeros;
-    const float* g10 = (yb >= 0 && xa >= 0) ? p.src + ((size_t)(unsigned)(yb + xa) * 96 + coff) : p.zeros;
-    const float* g11 = (yb >= 0 && xb >= 0) ? p.src + ((size_t)(unsigned)(yb + xb) * 96 + coff) : p.zeros;
-    r[0] = *(const f32x4*)g00;
-    r[1] = *(const f32x4*)g01;
-    r[2] = *(const f32x4*)g10;
-    r[3] = *(const f32x4*)g11;
+    // always load from a valid (clamped) address; zero padding is applied to the data in write_x
+    const int ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
+    r[0] = *(const f32x4*)(p.src + ((size_t)(unsigned)(ya_c + xa_c) * 96 + coff));
+    r[1] = *(const f32x4*)(p.src + ((size_t)(unsigned)(ya_c + xb_c) * 96 + coff));
+    r[2] = *(const f32x4*)(p.src + ((size_t)(unsigned)(yb_c + xa_c) * 96 + coff));
+    r[3] = *(const f32x4*)(p.src + ((size_t)(unsigned)(yb_c + xb_c) * 96 + coff));
   };
   auto write_x = [&](int it, int buf, const f32x4 (&r)[4]) {
     const int pos = it / 3;
     const int xi = pos >> 2, nu = pos & 3;
-    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3
-    const float sya = xi == 2 ? -1.f : 1.f, syb = (xi == 0 || xi == 3) ? -1.f : 1.f;
-    const float sxa = nu == 2 ? -1.f : 1.f, sxb = (nu == 0 || nu == 3) ? -1.f : 1.f;
+    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
+    const int ya = xi == 0 ? yo[0] : yo[1], yb = xi == 3 ? yo[3] : yo[2];
+    const int xa = nu == 0 ? xo[0] : xo[1], xb = nu == 3 ? xo[3] : xo[2];
+    const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = yb < 0 ? 0.f : ((xi == 0 || xi == 3) ? -1.f : 1.f);
+    const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = xb < 0 ? 0.f : ((nu == 0 || nu == 3) ? -1.f : 1.f);
     const f32x4 v = (r[0] * sxa + r[1] * sxb) * sya + (r[2] * sxa + r[3] * sxb) * syb;
     *(f32x4*)(Xb + buf * XB + srow * 128 + ps * 16) = v;
   };
@@ -96,16 +107,31 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoParams p) {
     }
   };
 
-  f32x4 mf[3][1], mg[3][1];            // position accumulators: feature tiles, gate tiles
+  f32x4 af[2][3], ag[2][3];            // position accumulators, two static sets (positions alternate between them)
   f32x4 of[2][2][3], og[2][2][3];      // output accumulators (a, b, tile)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    mf[j][0] = mg[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    af[0][j] = ag[0][j] = af[1][j] = ag[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) of[a][b][j] = og[a][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // fold a finished position accumulator set: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1]
+  auto fold = [&](f32x4 (&pf)[3], f32x4 (&pg)[3], int pos) {
+    const int xi = pos >> 2, nu = pos & 3;
+    const float ay0 = xi < 3 ? 1.f : 0.f, ay1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
+    const float ax0 = nu < 3 ? 1.f : 0.f, ax1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
+    const float c00 = ay0 * ax0, c01 = ay0 * ax1, c10 = ay1 * ax0, c11 = ay1 * ax1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      of[0][0][j] += pf[j] * c00; of[0][1][j] += pf[j] * c01;
+      of[1][0][j] += pf[j] * c10; of[1][1][j] += pf[j] * c11;
+      og[0][0][j] += pg[j] * c00; og[0][1][j] += pg[j] * c01;
+      og[1][0][j] += pg[j] * c10; og[1][1][j] += pg[j] * c11;
+      pf[j] = pg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
 
   f32x4 r[4];
   load_x(0, r);
@@ -113,36 +139,69 @@ __global__ __launch_bounds__(512) void wino_kernel(const WinoParams p) {
   write_x(0, 0, r);
   dma_wait_all();
   __syncthreads();
-  constexpr int NIT = 48;              // 16 positions x 3 chunks
-  for (int it = 0; it < NIT; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < NIT) {
-      load_x(it + 1, r);
-      dma_w(it + 1, buf ^ 1);
-    }
-    const char* Xt = Xb + buf * XB + tg * 2048;
-    mfma_chunk<3, 1>(mf, Wb + buf * WB + (3 * chh) * 2048, Xt, off0, off1);
-    mfma_chunk<3, 1>(mg, Wb + buf * WB + (6 + 3 * chh) * 2048, Xt, off0, off1);
-    const int pos = it / 3;
-    if (it - pos * 3 == 2) {
-      // inverse transform: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1]
-      const int xi = pos >> 2, nu = pos & 3;
-      const float ay0 = xi < 3 ? 1.f : 0.f, ay1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
-      const float ax0 = nu < 3 ? 1.f : 0.f, ax1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
-      const float c00 = ay0 * ax0, c01 = ay0 * ax1, c10 = ay1 * ax0, c11 = ay1 * ax1;
+  for (int pp = 0; pp < 8; ++pp) {               // position pairs; body unrolled so the accumulator sets are static
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int it = pp * 6 + k;
+      const int set = k / 3, chunk = k % 3;      // compile-time
+      const int pos = pp * 2 + set;
+      const int buf = k & 1;                     // == it & 1
+      const char* Xt = Xb + buf * XB + tg * 2048;
+      const char* Wf = Wb + buf * WB + (3 * chh) * 2048;
+      const char* Wg = Wb + buf * WB + (6 + 3 * chh) * 2048;
+      f32x4 wf[3], wg[3], xh;
+      // ---- k-half 0: 7 fragment reads, first 6 MFMAs
+      xh = *(const f32x4*)(Xt + off0);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        of[0][0][j] += mf[j][0] * c00; of[0][1][j] += mf[j][0] * c01;
-        of[1][0][j] += mf[j][0] * c10; of[1][1][j] += mf[j][0] * c11;
-        og[0][0][j] += mg[j][0] * c00; og[0][1][j] += mg[j][0] * c01;
-        og[1][0][j] += mg[j][0] * c10; og[1][1][j] += mg[j][0] * c11;
-        mf[j][0] = mg[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wf[j] = *(const f32x4*)(Wf + j * 2048 + off0);
+        wg[j] = *(const f32x4*)(Wg + j * 2048 + off0);
       }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][0], xh[0], af[set][j], 0, 0, 0);
+        ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j][0], xh[0], ag[set][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- in the shadow of the MFMA pipe: raw granules + W DMA of iteration it+1 (a whole iteration to land),
+      //      and the fold of the previous position (its MFMAs finished an iteration ago: no drain wait)
+      if (it + 1 < NIT) {
+        load_x(it + 1, r);
+        dma_w(it + 1, buf ^ 1);
+      }
+      if (chunk == 0 && it > 0) fold(af[set ^ 1], ag[set ^ 1], pos - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- k-half 1 fragments are fetched BEFORE the remaining 18 MFMAs of k-half 0 (both waves of a SIMD run in
+      //      lockstep, so an LDS read latency after the MFMAs would be fully exposed)
+      f32x4 wf1[3], wg1[3], xh1;
+      xh1 = *(const f32x4*)(Xt + off1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        wf1[j] = *(const f32x4*)(Wf + j * 2048 + off1);
+        wg1[j] = *(const f32x4*)(Wg + j * 2048 + off1);
+      }
+#pragma unroll
+      for (int e = 1; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xh[e], af[set][j], 0, 0, 0);
+          ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j][e], xh[e], ag[set][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[j][e], xh1[e], af[set][j], 0, 0, 0);
+          ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg1[j][e], xh1[e], ag[set][j], 0, 0, 0);
+        }
+      // ---- X tile of it+1 (hipcc waits for the 4 loads; the W DMA has had the same whole iteration to land)
+      if (it + 1 < NIT) write_x(it + 1, buf ^ 1, r);
+      dma_wait_all();
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (it + 1 < NIT) write_x(it + 1, buf ^ 1, r);
-    dma_wait_all();
-    __syncthreads();
   }
+  fold(af[1], ag[1], 15);
 
   // ---- epilogue: lane holds 4 consecutive channels of tile (lane&15): 2x2 output pixels
   const int q = lane >> 4;
