@@ -151,9 +151,20 @@ def main():
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         conv_ms = sum(r["total_ms"] for r in rep if r["kernel"].startswith(("gconv", "wino"))) / nprof
         conv_fl = sum(r["flops"] for r in rep if r["kernel"].startswith(("gconv", "wino"))) / nprof
+        # HBM bytes per launch of the dominant kernel come from the separate rocprofv3 --pmc passes
+        # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py -> profiles/pmc_traffic.json); null if not collected
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom["kernel"])
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 3),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None,
+                    "traffic": traffic,
+                    # the Winograd kernel executes 16 positions instead of 36 tap-products per 4 outputs: its MFMA
+                    # pipe does 4/9 of the algorithmic (reference-defined) FLOPs, so frac can exceed 1
+                    "executed_over_algorithmic": round(16.0 / 36.0, 4) if dom["kernel"].startswith("wino") else 1.0,
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "flops_per_launch": dom["flops"] / dom["launches"],

@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc CSV output per kernel (mean per dispatch).
 
-    python tools/pmc_summary.py gpurun_out/pmc1 [gpurun_out/pmc2 ...] > profiles/rNN_pmc.txt
-FETCH_SIZE is doubled (gfx950 counts 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section);
-FETCH/WRITE_SIZE are reported by rocprofv3 in KiB.
+    python tools/pmc_summary.py [--json profiles/pmc_traffic.json] gpurun_out/pmc1 gpurun_out/pmc2 ... > profiles/rNN_pmc.txt
+
+Corrections (MI355X_MICROARCH.md): FETCH_SIZE is doubled (gfx950 counts 128-B read requests at 64 B);
+FETCH/WRITE_SIZE are in KiB; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is summed
+over the 1024 SIMDs.  --json writes {kernel label: HBM bytes per launch (read+write)} for bench.py's
+roofline.traffic.
 """
 import collections
 import csv
+import json
 import os
 import sys
+
+LABELS = {"wino_kernel": "wino_n192", "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96",
+          "gconv_kernel<3": "gconv_n48", "gconv_kernel<2": "gconv_n24"}
 
 
 def load(d):
@@ -28,29 +35,44 @@ def load(d):
     return agg
 
 
-def main(dirs):
-    for d in dirs:
+def main(argv):
+    out_json = None
+    if argv and argv[0] == "--json":
+        out_json, argv = argv[1], argv[2:]
+    traffic = collections.defaultdict(float)
+    for d in argv:
         agg = load(d)
         print("== %s (mean per dispatch)" % d)
         for k in sorted(agg, key=lambda k: -sum(agg[k]["_dur_us"])):
             c = {n: sum(v) / len(v) for n, v in agg[k].items()}
             n = len(agg[k]["_dur_us"])
-            line = "%-34s n=%-4d dur=%8.1fus" % (k[:34], n, c.pop("_dur_us"))
+            dur_us = c.pop("_dur_us")
+            line = "%-34s n=%-4d dur=%8.1fus" % (k[:34], n, dur_us)
             if "GRBM_GUI_ACTIVE" in c:
-                line += "  clk=%.2fGHz" % (c["GRBM_GUI_ACTIVE"] / (c0 := agg[k]["_dur_us"] and (sum(agg[k]["_dur_us"]) / n)) / 1e3)
-            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-                # MFMA busy is summed over SIMDs (4/CU, 1024 total); GRBM_GUI_ACTIVE is chip cycles
-                line += "  mfma_busy=%.1f%%" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024))
+                xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+                line += "  clk=%.2fGHz" % (xcd_cycles / dur_us / 1e3)
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                    line += "  mfma_busy=%.1f%%" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / xcd_cycles)
             if "SQ_WAVE_CYCLES" in c:
                 wc = c["SQ_WAVE_CYCLES"]
                 line += "  wait_any=%.0f%% wait_inst=%.0f%% active=%.0f%%" % (
                     100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc, 100 * c["SQ_ACTIVE_INST_ANY"] / wc)
                 line += "  lds_conflict=%.1f%%" % (100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1))
+            lab = next((v for p, v in LABELS.items() if k.startswith(p)), None)
             if "FETCH_SIZE" in c:
-                line += "  HBM_read=%.1f MB (2x FETCH_SIZE)" % (2 * c["FETCH_SIZE"] * 1024 / 1e6)
+                b = 2 * c["FETCH_SIZE"] * 1024
+                line += "  HBM_read=%.1f MB (2x FETCH_SIZE)" % (b / 1e6)
+                if lab:
+                    traffic[lab] += b
             if "WRITE_SIZE" in c:
-                line += "  HBM_write=%.1f MB" % (c["WRITE_SIZE"] * 1024 / 1e6)
+                b = c["WRITE_SIZE"] * 1024
+                line += "  HBM_write=%.1f MB" % (b / 1e6)
+                if lab:
+                    traffic[lab] += b
             print(line)
+    if out_json:
+        json.dump({"unit": "bytes per launch (HBM read + write, rocprofv3 PMC, FETCH_SIZE x2)",
+                   "kernels": {k: round(v) for k, v in traffic.items()}}, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
