@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsketchedit_hip.so")
+# SKETCHEDIT_HIP_LIB points at another build of the same library (developer builds, e.g. tools/wino_trace.py)
+LIB_PATH = os.environ.get("SKETCHEDIT_HIP_LIB") or os.path.join(_HERE, "lib", "libsketchedit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["se_gconv.hip", "se_wino.hip", "se_attention.hip", "se_misc.hip", "se_api.hip"]
 

@@ -156,6 +156,11 @@ int fail(se_ctx* c, const char* fmt, ...) {
 bool wino_eligible_layer(const LayerDef& d);
 int pack_wino(se_ctx* c, Layer& L);
 
+int xcd_remap_enabled() {      // SE_XCD_REMAP=0 switches the XCD-aware tile order off (A/B measurements)
+  static const int v = getenv("SE_XCD_REMAP") ? atoi(getenv("SE_XCD_REMAP")) : 1;
+  return v;
+}
+
 int choose_cfg(int G) {
   if (G <= 16) return GC_N24;
   if (G <= 24) return GC_N48;
@@ -231,24 +236,25 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   HIPCHK(c, hipMemcpy(L.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   L.cfg = cfg; L.NP = NP; L.nch = nch; L.G = G; L.CGp = Cp / 4; L.T = T;
   L.packed = true;
-  if (wino_eligible_layer(d) && Cp == 96) return pack_wino(c, L);
+  if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
   return 0;
 }
 
 // Winograd F(2x2,3x3) weights: U[pos] = (G g G^T)[xi][nu] per (out, in) pair, packed per position like a 1x1
-// conv 96 -> 192 in the N=192 row order (features then gates) with the same slot swizzle.
+// conv Cin -> 192 (Cin = 96, or 192 for the two-source layers) in the N=192 row order (features then gates)
+// with the same slot swizzle.
 bool wino_eligible_layer(const LayerDef& d) {
-  return d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && d.act != ACT_NONE;
+  return d.k == 3 && d.stride == 1 && !d.up && (d.cin == 96 || d.cin == 192) && d.cout == 192 && d.act != ACT_NONE;
 }
 int pack_wino(se_ctx* c, Layer& L) {
   const LayerDef& d = L.def;
   static const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-  const int NP = 192, nch = 3;
+  const int NP = 192, nch = d.cin / 32;
   std::vector<float> img((size_t)16 * nch * NP * 32, 0.f);
   for (int n = 0; n < NP; ++n) {
     const int oc = out_channel_of_row(GC_N192, n, 96, 192);
-    for (int ic = 0; ic < 96; ++ic) {
-      const float* g = &L.w[((size_t)oc * 96 + ic) * 9];
+    for (int ic = 0; ic < d.cin; ++ic) {
+      const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
       float t[4][3];
       for (int i = 0; i < 4; ++i)
         for (int kx = 0; kx < 3; ++kx) t[i][kx] = Gm[i][0] * g[kx] + Gm[i][1] * g[3 + kx] + Gm[i][2] * g[6 + kx];
@@ -314,12 +320,15 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   if (!L.packed) return fail(c, "layer %s: weights not loaded", d.name);
   if ((C0 + C1) != L.CGp * 4) return fail(c, "layer %s: source channels %d+%d != packed %d", d.name, C0, C1, L.CGp * 4);
   static const bool use_wino = !(getenv("SE_WINOGRAD") && atoi(getenv("SE_WINOGRAD")) == 0);
-  if (use_wino && L.d_u && !src1 && C0 == 96 && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+  const bool wino_src_ok = (!src1 && C0 == 96 && d.cin == 96) || (src1 && C0 == 96 && C1 == 96 && d.cin == 192);
+  if (use_wino && L.d_u && wino_src_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
-    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_b; wp.dst = dst; wp.zeros = c->zeros;
+    wp.src = src0; wp.src1 = src1; wp.src1_vec = src1_vec;
+    wp.upk = L.d_u; wp.bias = L.d_b; wp.dst = dst; wp.zeros = c->zeros;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+    wp.xcd = xcd_remap_enabled();
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
     set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name);
     HIPCHK(c, launch_wino(wp, c->st));
@@ -343,6 +352,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   p.ushift = 0;
   p.Hlim = Hin; p.Wlim = Win;
   p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * p.Ho * p.Wo;
+  p.xcd = xcd_remap_enabled();
   // algorithmic cost as the reference defines the layer (3x3 on the upsampled grid for gen_deconv)
   set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k,
                   4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name);

@@ -42,6 +42,17 @@ DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEVFN float elu_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
 DEVFN float sigmoid_fast(float x) { return fast_rcp(1.f + fast_exp(-x)); }
 
+// ---- XCD-aware tile order ---------------------------------------------------------------------------
+// The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md); each XCD has its own L2.
+// Remap so that every XCD walks one CONTIGUOUS eighth of the tile list: vertically adjacent tiles (which
+// re-read the same input rows through the 3x3 taps) then share an L2.  Bijective for any grid size; only
+// speed depends on the placement assumption, never correctness.
+DEVFN int xcd_tile(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---- MFMA core ------------------------------------------------------------------------------------
 // One 32-k chunk for a wave tile of NT (rows: packed channels) x PT (cols: pixels) 16x16 tiles.
 // Wt: [NT*16][128 B] tile, Xt: this wave's [PT*16][128 B] tile, both with the 16-B slot of row r

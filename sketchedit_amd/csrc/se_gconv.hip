@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile_base = blockIdx.x * PIX;
+  const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * PIX;
   // sub-pixel upsample form: this workgroup computes output pixels (2yy+py, 2xx+px); taps (a,b) in {0,1}^2 read
   // source (yy + a - 1 + py, xx + b - 1 + px) with weights summed over the 3x3 taps that collapse onto it
   const int py = p.up2 ? (int)(blockIdx.y >> 1) : 0, px = p.up2 ? (int)(blockIdx.y & 1) : 0;

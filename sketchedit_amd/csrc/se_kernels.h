@@ -53,6 +53,7 @@ struct GConvParams {
   int G;               // gated (stored) output channels
   int act;             // 0 ELU, 1 ReLU
   int total_pix;       // B*Ho*Wo
+  int xcd;             // 1: XCD-aware tile order (se_device.h xcd_tile)
 };
 
 enum GConvCfg { GC_N192 = 0, GC_N96 = 1, GC_N48 = 2, GC_N24 = 3 };
@@ -67,7 +68,9 @@ hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st);
 // ---------------------------------------------------------------------------------------------
 struct WinoParams {
   const float* src;    // NHWC [B][h][w][96]
-  const float* upk;    // [16 positions][3 chunks][192 packed rows][32]: G g G^T, LDS image (pre-swizzled)
+  const float* src1;   // optional second 96-channel source (channel concat): NHWC tensor, or [B][96] vector; else null
+  int src1_vec;        // src1 is a per-image vector (spatially constant, zero padded like a tensor)
+  const float* upk;    // [16 positions][3 or 6 chunks][192 packed rows][32]: G g G^T, LDS image (pre-swizzled)
   const float* bias;   // [192] packed-row order (features, then gates)
   float* dst;          // NHWC [B][h][w][96]
   const float* zeros;
@@ -75,6 +78,7 @@ struct WinoParams {
   int th, tw;          // tile grid h/2 x w/2
   int total_tiles;     // B*th*tw
   int act;             // 0 ELU, 1 ReLU
+  int xcd;             // 1: XCD-aware tile order
 };
 hipError_t launch_wino(const WinoParams& p, hipStream_t st);
 

@@ -29,12 +29,33 @@
 
 #include <cstdlib>
 
+// Developer aid, compiled only with -DSE_WINO_TRACE (tools/wino_trace.py builds a separate debug library):
+// s_memtime stamps of block 0 / wave 0 at the phase boundaries of every iteration.
+#ifdef SE_WINO_TRACE
+__device__ unsigned long long g_wino_trace[96 * 8];
+extern "C" int se_debug_wino_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_trace), sizeof(unsigned long long) * 48 * 8);
+}
+#define WINO_STAMP(k)                                                   \
+  do {                                                                  \
+    if (blockIdx.x == 0 && w == 0) {                                    \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+      if (lane == 0) g_wino_trace[it * 8 + (k)] = t_;                   \
+    }                                                                   \
+  } while (0)
+#else
+#define WINO_STAMP(k)
+#endif
+
 namespace se {
 
+// NCHK = 32-channel chunks per position: 3 for one 96-channel source, 6 for the two-source layers
+// (conv11: features + pooled style vector, allconv11: cat([x_hallu, pm]) -- editline_g.py:166-167,211).
+template <int NCHK>
 __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   constexpr int TILES = 64;
   constexpr int XB = TILES * 128, WB = 192 * 128;
-  constexpr int NIT = 48;              // 16 positions x 3 chunks
+  constexpr int NIT = 16 * NCHK;       // 16 positions x NCHK chunks
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   char* Wb = smem + 2 * XB;
@@ -42,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chh = w & 1, tg = w >> 1;          // channel half, tile group
-  const int tile_base = blockIdx.x * TILES;
+  const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
   const int tpi = p.th * p.tw;                 // tiles per image
 
   // tile -> (batch, first output pixel).  iy walks the tile grid; y0 = 2d*(iy/d) + iy%d
@@ -59,10 +80,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   const int srow = tid >> 3, ps = tid & 7;
   const int s_log = ps ^ ((srow >> 1) & 7);
   int yo[4], xo[4];     // pixel-row offset (b*h + y)*w resp. x of the 4x4 input tile, or -1 if outside / invalid tile
+  int bimg;             // batch index of this lane's tile (address of the per-image vector source)
   {
     const int t = tile_base + srow;
     int b, y0, x0;
     tile_origin(t < p.total_tiles ? t : 0, b, y0, x0);
+    bimg = b;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
@@ -75,20 +98,27 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   frag_offsets(lane, off0, off1);
 
   auto load_x = [&](int it, f32x4 (&r)[4]) {
-    const int pos = it / 3, chunk = it - pos * 3;          // uniform
+    const int pos = it / NCHK, chunk = it - pos * NCHK;    // uniform
     const int xi = pos >> 2, nu = pos & 3;
     const int ya = xi == 0 ? yo[0] : yo[1], yb = xi == 3 ? yo[3] : yo[2];
     const int xa = nu == 0 ? xo[0] : xo[1], xb = nu == 3 ? xo[3] : xo[2];
-    const int coff = (chunk * 8 + s_log) * 4;
     // always load from a valid (clamped) address; zero padding is applied to the data in write_x
     const int ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
-    r[0] = *(const f32x4*)(p.src + ((size_t)(unsigned)(ya_c + xa_c) * 96 + coff));
-    r[1] = *(const f32x4*)(p.src + ((size_t)(unsigned)(ya_c + xb_c) * 96 + coff));
-    r[2] = *(const f32x4*)(p.src + ((size_t)(unsigned)(yb_c + xa_c) * 96 + coff));
-    r[3] = *(const f32x4*)(p.src + ((size_t)(unsigned)(yb_c + xb_c) * 96 + coff));
+    if (NCHK == 6 && chunk >= 3 && p.src1_vec) {
+      // spatially constant second source (pooled style vector): one value per image, still zero padded
+      const f32x4 v = *(const f32x4*)(p.src1 + ((size_t)bimg * 96 + ((chunk - 3) * 8 + s_log) * 4));
+      r[0] = r[1] = r[2] = r[3] = v;
+      return;
+    }
+    const float* base = (NCHK == 6 && chunk >= 3) ? p.src1 : p.src;
+    const int coff = (((NCHK == 6 && chunk >= 3) ? chunk - 3 : chunk) * 8 + s_log) * 4;
+    r[0] = *(const f32x4*)(base + ((size_t)(unsigned)(ya_c + xa_c) * 96 + coff));
+    r[1] = *(const f32x4*)(base + ((size_t)(unsigned)(ya_c + xb_c) * 96 + coff));
+    r[2] = *(const f32x4*)(base + ((size_t)(unsigned)(yb_c + xa_c) * 96 + coff));
+    r[3] = *(const f32x4*)(base + ((size_t)(unsigned)(yb_c + xb_c) * 96 + coff));
   };
   auto write_x = [&](int it, int buf, const f32x4 (&r)[4]) {
-    const int pos = it / 3;
+    const int pos = it / NCHK;
     const int xi = pos >> 2, nu = pos & 3;
     // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
     const int ya = xi == 0 ? yo[0] : yo[1], yb = xi == 3 ? yo[3] : yo[2];
@@ -141,15 +171,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   __syncthreads();
   for (int pp = 0; pp < 8; ++pp) {               // position pairs; body unrolled so the accumulator sets are static
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int it = pp * 6 + k;
-      const int set = k / 3, chunk = k % 3;      // compile-time
+    for (int k = 0; k < 2 * NCHK; ++k) {
+      const int it = pp * 2 * NCHK + k;
+      const int set = k / NCHK, chunk = k % NCHK;      // compile-time
       const int pos = pp * 2 + set;
       const int buf = k & 1;                     // == it & 1
       const char* Xt = Xb + buf * XB + tg * 2048;
       const char* Wf = Wb + buf * WB + (3 * chh) * 2048;
       const char* Wg = Wb + buf * WB + (6 + 3 * chh) * 2048;
       f32x4 wf[3], wg[3], xh;
+      WINO_STAMP(0);
       // ---- k-half 0: 7 fragment reads, first 6 MFMAs
       xh = *(const f32x4*)(Xt + off0);
 #pragma unroll
@@ -163,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
         ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j][0], xh[0], ag[set][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      WINO_STAMP(1);
       // ---- in the shadow of the MFMA pipe: raw granules + W DMA of iteration it+1 (a whole iteration to land),
       //      and the fold of the previous position (its MFMAs finished an iteration ago: no drain wait)
       if (it + 1 < NIT) {
@@ -171,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       }
       if (chunk == 0 && it > 0) fold(af[set ^ 1], ag[set ^ 1], pos - 1);
       __builtin_amdgcn_sched_barrier(0);
+      WINO_STAMP(2);
       // ---- k-half 1 fragments are fetched BEFORE the remaining 18 MFMAs of k-half 0 (both waves of a SIMD run in
       //      lockstep, so an LDS read latency after the MFMAs would be fully exposed)
       f32x4 wf1[3], wg1[3], xh1;
@@ -194,10 +227,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
           af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[j][e], xh1[e], af[set][j], 0, 0, 0);
           ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg1[j][e], xh1[e], ag[set][j], 0, 0, 0);
         }
+      WINO_STAMP(3);
       // ---- X tile of it+1 (hipcc waits for the 4 loads; the W DMA has had the same whole iteration to land)
       if (it + 1 < NIT) write_x(it + 1, buf ^ 1, r);
+      WINO_STAMP(4);
       dma_wait_all();
+      WINO_STAMP(5);
       __syncthreads();
+      WINO_STAMP(6);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -232,18 +269,23 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   }
 }
 
-hipError_t launch_wino(const WinoParams& p, hipStream_t st) {
+template <int NCHK>
+static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 64 * 128 + 2 * 192 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<NCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int grid = (p.total_tiles + 63) / 64;
   ProfScope ps_(st, PL_WINO_N192);
-  hipLaunchKernelGGL(wino_kernel, dim3(grid), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL(wino_kernel<NCHK>, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
+}
+
+hipError_t launch_wino(const WinoParams& p, hipStream_t st) {
+  return p.src1 ? launch_wino_t<6>(p, st) : launch_wino_t<3>(p, st);
 }
 
 }  // namespace se

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Developer aid: per-phase cycle trace of the Winograd kernel (block 0 / wave 0, s_memtime stamps).
+
+    python tools/wino_trace.py build      # cross-compiles tools/_build/libse_trace.so with -DSE_WINO_TRACE (no GPU needed)
+    python tools/wino_trace.py run        # on the GPU box: runs one 96->192 3x3 layer (B=32, 64x64) and prints the table
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tools", "_build", "libse_trace.so")
+NAMES = ["frag+6mfma", "shadow(ld/dma/fold)", "42 mfma", "x-write", "dma-wait", "barrier"]
+
+
+def build():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    csrc = os.path.join(ROOT, "sketchedit_amd", "csrc")
+    srcs = [os.path.join(csrc, s) for s in ("se_gconv.hip", "se_wino.hip", "se_attention.hip", "se_misc.hip", "se_api.hip")]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSE_WINO_TRACE",
+                           "-o", SO] + srcs)
+    print("built", SO)
+
+
+def run():
+    os.environ["SKETCHEDIT_HIP_LIB"] = SO
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    from sketchedit_amd import synth
+    from sketchedit_amd._lib import Engine
+    eng = Engine(0)
+    a = 1.5 / np.sqrt(96 * 9)
+    w = synth.uniform(1, "t.w", (192, 96, 3, 3), -a, a)
+    b = synth.uniform(1, "t.b", (192,), -0.1, 0.1)
+    x = torch.from_numpy(synth.uniform(1, "t.x", (32, 96, 64, 64), -1, 1)).cuda()
+    for _ in range(3):
+        eng.gated_conv2d(x, w, b)
+    torch.cuda.synchronize()
+    lib = ctypes.CDLL(SO)
+    buf = (ctypes.c_ulonglong * (48 * 8))()
+    assert lib.se_debug_wino_trace(buf) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(48, 8).astype(np.int64)
+    print("it   " + "  ".join("%-19s" % n for n in NAMES) + "  total")
+    for it in range(6, 24):
+        d = [t[it, k + 1] - t[it, k] for k in range(6)]
+        print("%2d   " % it + "  ".join("%-19d" % v for v in d) + "  %d" % (t[it, 6] - t[it, 0]))
+    print("whole loop: %d cycles, mean per iteration %.0f" % (t[47, 6] - t[0, 0], (t[47, 6] - t[0, 0]) / 48.0))
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1]]()
