@@ -22,9 +22,14 @@
 // waiting for the pipe to drain before the inverse adds and ~250 issuing the DMA): the fold of position P runs in
 // the MFMA shadow of the NEXT iteration (the accumulator is double-buffered), and the DMA / global-load issue for
 // iteration it+1 sits between the two MFMA halves, fenced with sched_barrier so hipcc keeps it there.
-// Other layouts tried and measured slower on this kernel (kept out of the tree): raw granules resident in
-// registers with a 3-deep W ring (spills at 256 VGPRs), 16-wave workgroups with 3 channel tiles per wave and an
-// LDS gate exchange (spills at 128 VGPRs), two 4-wave workgroups per CU (344 VGPRs needed).
+// Other layouts tried on the GPU and NOT faster (kept out of the tree; all land at ~205-235 us per launch with the
+// MFMA pipe ~58 % busy): raw granules resident in registers with a 3-deep W ring (spills at 256 VGPRs), 16-wave
+// workgroups with 3 channel tiles per wave and an LDS gate exchange (spills at 128 VGPRs), two 4-wave workgroups
+// per CU (344 VGPRs needed), and an "LDS patch" form (raw 64 KiB input patch staged once per chunk, B fragments
+// built straight from it, no global load / X tile in the loop, one or two positions per barrier): identical
+// time, i.e. neither the gather traffic nor the barrier count limits this kernel -- what all variants share is
+// short MFMA bursts (24 per k-half) behind freshly issued LDS fragment reads with both waves of a SIMD in phase
+// and no register room to double-buffer the fragments.
 #include "se_device.h"
 
 #include <cstdlib>

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Developer aid: per-phase cycle trace of the Winograd kernel (block 0 / wave 0, s_memtime stamps).
+"""Developer aid: per-phase cycle trace of the Winograd kernels (block 0 / wave 0, s_memtime stamps).
 
     python tools/wino_trace.py build      # cross-compiles tools/_build/libse_trace.so with -DSE_WINO_TRACE (no GPU needed)
-    python tools/wino_trace.py run        # on the GPU box: runs one 96->192 3x3 layer (B=32, 64x64) and prints the table
+    python tools/wino_trace.py run        # on the GPU box: runs one 96->192 3x3 layer (B=32, 64x64) and prints the tables
 """
 import ctypes
 import os
@@ -11,16 +11,24 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tools", "_build", "libse_trace.so")
-NAMES = ["frag+6mfma", "shadow(ld/dma/fold)", "42 mfma", "x-write", "dma-wait", "barrier"]
 
 
 def build():
+    sys.path.insert(0, ROOT)
+    from sketchedit_amd import _lib
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    csrc = os.path.join(ROOT, "sketchedit_amd", "csrc")
-    srcs = [os.path.join(csrc, s) for s in ("se_gconv.hip", "se_wino.hip", "se_attention.hip", "se_misc.hip", "se_api.hip")]
+    srcs = [os.path.join(_lib.CSRC, s) for s in _lib.SOURCES]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSE_WINO_TRACE",
                            "-o", SO] + srcs)
     print("built", SO)
+
+
+def table(t, names, nstamp):
+    print("it   " + "  ".join("%-16s" % n for n in names) + "  total")
+    for it in range(6, 24):
+        d = [t[it, k + 1] - t[it, k] for k in range(nstamp - 1)]
+        print("%2d   " % it + "  ".join("%-16d" % v for v in d) + "  %d" % (t[it, nstamp - 1] - t[it, 0]))
+    print("iterations 0..46: %d cycles, mean per iteration %.0f" % (t[46, nstamp - 1] - t[0, 0], (t[46, nstamp - 1] - t[0, 0]) / 47.0))
 
 
 def run():
@@ -30,23 +38,20 @@ def run():
     import torch
     from sketchedit_amd import synth
     from sketchedit_amd._lib import Engine
-    eng = Engine(0)
     a = 1.5 / np.sqrt(96 * 9)
     w = synth.uniform(1, "t.w", (192, 96, 3, 3), -a, a)
     b = synth.uniform(1, "t.b", (192,), -0.1, 0.1)
     x = torch.from_numpy(synth.uniform(1, "t.x", (32, 96, 64, 64), -1, 1)).cuda()
+    lib = ctypes.CDLL(SO)
+    buf = (ctypes.c_ulonglong * (48 * 8))()
+    eng = Engine(0)
     for _ in range(3):
         eng.gated_conv2d(x, w, b)
     torch.cuda.synchronize()
-    lib = ctypes.CDLL(SO)
-    buf = (ctypes.c_ulonglong * (48 * 8))()
     assert lib.se_debug_wino_trace(buf) == 0
     t = np.frombuffer(buf, dtype=np.uint64).reshape(48, 8).astype(np.int64)
-    print("it   " + "  ".join("%-19s" % n for n in NAMES) + "  total")
-    for it in range(6, 24):
-        d = [t[it, k + 1] - t[it, k] for k in range(6)]
-        print("%2d   " % it + "  ".join("%-19d" % v for v in d) + "  %d" % (t[it, 6] - t[it, 0]))
-    print("whole loop: %d cycles, mean per iteration %.0f" % (t[47, 6] - t[0, 0], (t[47, 6] - t[0, 0]) / 48.0))
+    print("== wino_kernel (se_wino.hip)")
+    table(t, ["frag+6mfma", "shadow ld/dma", "42 mfma", "x-write", "dma-wait", "barrier"], 7)
 
 
 if __name__ == "__main__":
