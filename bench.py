@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--layers", action="store_true", help="add the per-layer timing table to the JSON line")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (test aid)")
+    ap.add_argument("--check-gather", action="store_true", help="rank 0 verifies the gathered outputs (test aid)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,17 +88,23 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     dist = None
+    # --device / --backend exist only to exercise the N > 1 code path on a 1-GPU box (both ranks on cuda:0 over
+    # gloo); the driver's runs use the defaults: one rank per GPU (LOCAL_RANK) over nccl = RCCL.
+    dev_index = local_rank if args.device < 0 else args.device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     B, S = args.batch, args.size
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
     eng.load_state_dict("M", synth.make_state_dict("M", 0))
     eng.load_state_dict("G", synth.make_state_dict("G", 0))
     img_h, sk_h = synth.make_inputs(B, S, S, seed=1234, first_index=rank * B)   # shard = rows of the global batch
@@ -103,15 +112,21 @@ def main():
     sk = torch.from_numpy(sk_h).to(dev)
     out = {"composed": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
            "mask": torch.empty((B, 1, S, S), dtype=torch.float32, device=dev)}
+    gathered = {}
     if world > 1:
-        g_comp = torch.empty((world * B, 3, S, S), dtype=torch.float32, device=dev)
-        g_mask = torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev)
+        gathered["composed"] = torch.empty((world * B, 3, S, S), dtype=torch.float32, device=dev)
+        gathered["mask"] = torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev)
 
     def step():
         eng.inference(img, sk, FLAGS, out=out)
-        if world > 1:
-            dist.all_gather_into_tensor(g_comp, out["composed"])
-            dist.all_gather_into_tensor(g_mask, out["mask"])
+        if world > 1:      # the only exchange of the path: all-gather of the outputs
+            for k in ("composed", "mask"):
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(gathered[k], out[k])
+                else:              # gloo cannot all-gather device tensors: stage through the host (test aid only)
+                    parts = [torch.empty(out[k].shape, dtype=torch.float32) for _ in range(world)]
+                    dist.all_gather(parts, out[k].cpu())
+                    gathered[k].copy_(torch.cat(parts, 0))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -128,9 +143,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if args.check_gather:
+            # every rank finds its own rows in the gathered batch; rank 0 recomputes image 0 of rank 1's shard
+            ok = torch.equal(gathered["composed"][rank * B:(rank + 1) * B], out["composed"]) and \
+                torch.equal(gathered["mask"][rank * B:(rank + 1) * B], out["mask"])
+            if rank == 0:
+                i1, s1 = synth.make_inputs(1, S, S, seed=1234, first_index=B)
+                r1 = eng.inference(torch.from_numpy(i1).to(dev), torch.from_numpy(s1).to(dev), FLAGS)
+                ok = ok and torch.equal(r1["composed"], gathered["composed"][B:B + 1])
+            f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            if float(f.item()) != 1.0:
+                raise SystemExit("gathered outputs do not match the per-rank outputs")
 
     # ---- per-kernel timing pass (HIP events on the launch stream), not part of the timed region
     roofline, kernels = None, None
