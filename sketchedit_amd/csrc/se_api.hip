@@ -321,7 +321,9 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   if ((C0 + C1) != L.CGp * 4) return fail(c, "layer %s: source channels %d+%d != packed %d", d.name, C0, C1, L.CGp * 4);
   static const bool use_wino = !(getenv("SE_WINOGRAD") && atoi(getenv("SE_WINOGRAD")) == 0);
   const bool wino_src_ok = (!src1 && C0 == 96 && d.cin == 96) || (src1 && C0 == 96 && C1 == 96 && d.cin == 192);
-  if (use_wino && L.d_u && wino_src_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+  // the kernel addresses a source through 32-bit byte offsets (96 floats per pixel)
+  const bool wino_addr_ok = (long long)B * Hin * Win * 384 < (1ll << 31);
+  if (use_wino && L.d_u && wino_src_ok && wino_addr_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.src1 = src1; wp.src1_vec = src1_vec;
@@ -592,6 +594,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_u) (void)hipFree(kv.second.d_u);
     }
   if (c->zeros) (void)hipFree(c->zeros);
+  for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -707,8 +710,13 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
 int se_profile_enable(se_ctx* c, int on) {
   if (!c) return 1;
   std::lock_guard<std::mutex> lk(c->mu);
-  for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  HIPCHK(c, hipSetDevice(c->device));
   c->prof.recs.clear();
+  c->prof.used = 0;
+  if (on && c->prof.pool.empty()) {
+    c->prof.pool.resize(2 * 1024);           // enough for ~12 forwards of ~80 launches
+    for (auto& e : c->prof.pool) HIPCHK(c, hipEventCreate(&e));
+  }
   c->prof.on = on != 0;
   return 0;
 }

@@ -27,6 +27,19 @@ DEVFN void glds16(const void* gsrc, unsigned lds_addr) {
       : "v"(gsrc), "s"(lds_addr)
       : "memory");
 }
+// same, scalar base + 32-bit lane offset addressing (no VALU address arithmetic at the call site)
+DEVFN void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
 DEVFN void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 DEVFN unsigned lds_addr_of(const void* p) {

@@ -19,6 +19,8 @@ const char* prof_label_name(int l);
 struct Profiler {
   struct Rec { int label; const char* name; double flops; double bytes; hipEvent_t a, b; };
   std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;   // pre-created events (se_profile_enable), handed out two per launch
+  size_t used = 0;
   bool on = false;
 };
 void set_profiler(Profiler* p);          // thread-local; set by the API under the ctx lock

@@ -27,7 +27,11 @@ ProfScope::ProfScope(hipStream_t s, int label) : st(s) {
   if (!p || !p->on) return;
   Profiler::Rec r;
   r.label = label; r.name = nm; r.flops = fl; r.bytes = by;
-  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  // events come from a pool created at se_profile_enable(): creating them here cost ~10 us of host time per launch,
+  // let the GPU run dry between kernels and inflated the measured durations of short kernels
+  if (p->used + 2 > p->pool.size()) return;
+  r.a = p->pool[p->used++];
+  r.b = p->pool[p->used++];
   (void)hipEventRecord(r.a, st);
   p->recs.push_back(r);
   idx = (int)p->recs.size() - 1;

@@ -11,45 +11,61 @@
 //
 // One workgroup = 8 waves (two per SIMD) = 64 tiles x all 192 packed channels; wave w owns 16 tiles (MFMA columns)
 // and one half of the channels (3 feature tiles + their 3 gate tiles, so the gate is a register epilogue).
-// Loop over it = (position, 32-k chunk), 48 iterations, double-buffered LDS, one barrier per iteration:
+// Loop over it = (position, 32-k chunk), 48 (96 with two sources) iterations, fully unrolled, three-slot LDS ring,
+// one barrier per iteration:
 //   * X tile [64 tiles][32 k]: each lane builds ONE granule = (B^T x B) at this position from 4 raw input granules
-//     (global loads issued at the start of the previous iteration) and writes it to LDS -- the input transform is
-//     fused, no transformed tensor ever exists in HBM;
+//     (global loads issued an iteration earlier) and writes it to LDS -- the input transform is fused, no
+//     transformed tensor ever exists in HBM;
 //   * W tile [192][32 k] of the host-transformed weights G g G^T by LDS-DMA;
-//   * 48 MFMAs per wave into the position accumulator; after the last chunk of a position it is folded into the
-//     four output accumulators with the A^T coefficients (inverse transform in registers).
-// Schedule (from s_memtime stamps: of ~4.1k cycles per iteration only 3.1k are MFMA pipe time; ~1.0-1.6k was spent
-// waiting for the pipe to drain before the inverse adds and ~250 issuing the DMA): the fold of position P runs in
-// the MFMA shadow of the NEXT iteration (the accumulator is double-buffered), and the DMA / global-load issue for
-// iteration it+1 sits between the two MFMA halves, fenced with sched_barrier so hipcc keeps it there.
-// Other layouts tried on the GPU and NOT faster (kept out of the tree; all land at ~205-235 us per launch with the
-// MFMA pipe ~58 % busy): raw granules resident in registers with a 3-deep W ring (spills at 256 VGPRs), 16-wave
-// workgroups with 3 channel tiles per wave and an LDS gate exchange (spills at 128 VGPRs), two 4-wave workgroups
-// per CU (344 VGPRs needed), and an "LDS patch" form (raw 64 KiB input patch staged once per chunk, B fragments
-// built straight from it, no global load / X tile in the loop, one or two positions per barrier): identical
-// time, i.e. neither the gather traffic nor the barrier count limits this kernel -- what all variants share is
-// short MFMA bursts (24 per k-half) behind freshly issued LDS fragment reads with both waves of a SIMD in phase
-// and no register room to double-buffer the fragments.
+//   * 48 MFMAs per wave into the position accumulator; at the start of the next position it is folded into the four
+//     output accumulators with the A^T coefficients (inverse transform in registers).
+// What the s_memtime traces (tools/wino_trace.py) showed, and what the schedule does about it:
+//   1. fp32 MFMA and VALU do not overlap on a SIMD: a wave's VALU instruction does not issue while its SIMD partner
+//      streams v_mfma_f32_16x16x4_f32 (s_setprio does not change that), and inside one wave every VALU instruction
+//      is a lost MFMA slot.  So the loop carries as few VALU instructions as possible (~25 per wave and iteration,
+//      was ~70): gather offsets and B^T factors are computed once per POSITION (source offsets live in LDS, not in
+//      registers), loads and DMA use scalar-base + 32-bit-offset addressing, the first MFMA of a position takes
+//      C = 0 instead of zeroed registers, the fold generates only its 12 (of 16) non-zero terms, and there is one
+//      accumulator set -- a second one to "hide" the fold buys nothing and costs 24 registers.
+//   2. A wave that issues its 7 vector-memory instructions back to back (all 8 waves do so at the same point) stalls
+//      ~1000 cycles in front of the full vector-memory queue and cannot issue MFMAs meanwhile: they are issued one
+//      per MFMA group.
+//   3. The k-half 0 fragments of the next iteration are read before the barrier (its slot was published one barrier
+//      earlier), so the MFMA stream continues straight across the barrier.
+// Per-launch time 200 -> 168 us (B=32, 64x64; 115 TF/s executed = 73 % of the fp32 MFMA peak, 258 TF/s in direct-
+// convolution terms).  Tried and NOT faster: a ping-pong split (waves 0-3 / 4-7 one phase apart, two barriers per
+// iteration: 237 us), two 4-wave workgroups per CU, 16-wave workgroups with an LDS gate exchange, raw granules in
+// registers, an "LDS patch" form without global loads in the loop, two positions per barrier.
 #include "se_device.h"
 
 #include <cstdlib>
 
 // Developer aid, compiled only with -DSE_WINO_TRACE (tools/wino_trace.py builds a separate debug library):
-// s_memtime stamps of block 0 / wave 0 at the phase boundaries of every iteration.
+// s_memtime stamps of block 0 / waves 0 and 4 (the two waves of SIMD 0) at the phase boundaries of every iteration.
 #ifdef SE_WINO_TRACE
 __device__ unsigned long long g_wino_trace[96 * 8];
 extern "C" int se_debug_wino_trace(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_trace), sizeof(unsigned long long) * 48 * 8);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_trace), sizeof(unsigned long long) * 96 * 8);
 }
+// stamps go to LDS (a global store per stamp would sit in vmcnt and distort the waits being measured)
+#define WINO_TRACE_LDS (3 * 64 * 128 + 3 * 192 * 128 + 8 * 512 * 4)
 #define WINO_STAMP(k)                                                   \
   do {                                                                  \
-    if (blockIdx.x == 0 && w == 0) {                                    \
+    if (blockIdx.x == 0 && (w & 3) == 0) {                              \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
-      if (lane == 0) g_wino_trace[it * 8 + (k)] = t_;                   \
+      if (lane == 0) ((unsigned long long*)(smem + WINO_TRACE_LDS))[((w >> 2) * 48 + it) * 8 + (k)] = t_; \
     }                                                                   \
   } while (0)
+#define WINO_TRACE_DUMP()                                               \
+  do {                                                                  \
+    if (blockIdx.x == 0 && (w & 3) == 0)                                \
+      for (int i_ = lane; i_ < 48 * 8; i_ += 64)                        \
+        g_wino_trace[(w >> 2) * 48 * 8 + i_] = ((unsigned long long*)(smem + WINO_TRACE_LDS))[(w >> 2) * 48 * 8 + i_]; \
+  } while (0)
 #else
+#define WINO_TRACE_LDS 0
 #define WINO_STAMP(k)
+#define WINO_TRACE_DUMP()
 #endif
 
 namespace se {
@@ -63,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   constexpr int NIT = 16 * NCHK;       // 16 positions x NCHK chunks
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
-  char* Wb = smem + 2 * XB;
+  char* Wb = smem + 3 * XB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +100,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   // ---- staging role: granule (row = tile tid>>3, physical slot tid&7)
   const int srow = tid >> 3, ps = tid & 7;
   const int s_log = ps ^ ((srow >> 1) & 7);
-  int yo[4], xo[4];     // pixel-row offset (b*h + y)*w resp. x of the 4x4 input tile, or -1 if outside / invalid tile
+  // Source offsets of the 4x4 input tile, kept in LDS (read once per position; registers are the scarce resource):
+  //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or -1 if outside / invalid tile
+  //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
+  int* Ysrc = (int*)(smem + 3 * XB + 3 * WB);
+  int* Xsrc = Ysrc + 4 * 512;
+  const unsigned lane_coff = (unsigned)s_log * 16u;
   int bimg;             // batch index of this lane's tile (address of the per-image vector source)
   {
     const int t = tile_base + srow;
@@ -94,156 +115,212 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
-      yo[i] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (b * p.h + y) * p.w : -1;
-      xo[i] = ((unsigned)x < (unsigned)p.w) ? x : -1;
+      Ysrc[i * 512 + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + lane_coff) : -1;
+      Xsrc[i * 512 + tid] = ((unsigned)x < (unsigned)p.w) ? x * 384 : -1;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
   int off0, off1;
   frag_offsets(lane, off0, off1);
 
-  auto load_x = [&](int it, f32x4 (&r)[4]) {
-    const int pos = it / NCHK, chunk = it - pos * NCHK;    // uniform
-    const int xi = pos >> 2, nu = pos & 3;
-    const int ya = xi == 0 ? yo[0] : yo[1], yb = xi == 3 ? yo[3] : yo[2];
-    const int xa = nu == 0 ? xo[0] : xo[1], xb = nu == 3 ? xo[3] : xo[2];
-    // always load from a valid (clamped) address; zero padding is applied to the data in write_x
-    const int ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
-    if (NCHK == 6 && chunk >= 3 && p.src1_vec) {
-      // spatially constant second source (pooled style vector): one value per image, still zero padded
-      const f32x4 v = *(const f32x4*)(p.src1 + ((size_t)bimg * 96 + ((chunk - 3) * 8 + s_log) * 4));
-      r[0] = r[1] = r[2] = r[3] = v;
-      return;
-    }
-    const float* base = (NCHK == 6 && chunk >= 3) ? p.src1 : p.src;
-    const int coff = (((NCHK == 6 && chunk >= 3) ? chunk - 3 : chunk) * 8 + s_log) * 4;
-    r[0] = *(const f32x4*)(base + ((size_t)(unsigned)(ya_c + xa_c) * 96 + coff));
-    r[1] = *(const f32x4*)(base + ((size_t)(unsigned)(ya_c + xb_c) * 96 + coff));
-    r[2] = *(const f32x4*)(base + ((size_t)(unsigned)(yb_c + xa_c) * 96 + coff));
-    r[3] = *(const f32x4*)(base + ((size_t)(unsigned)(yb_c + xb_c) * 96 + coff));
-  };
-  auto write_x = [&](int it, int buf, const f32x4 (&r)[4]) {
-    const int pos = it / NCHK;
-    const int xi = pos >> 2, nu = pos & 3;
+  // fp32 MFMA and VALU instructions share the SIMD's issue time on gfx950 (a wave's VALU does not issue while its
+  // SIMD partner streams fp32 MFMAs, and inside one wave every VALU instruction is a lost MFMA slot), so the loop
+  // keeps the VALU count minimal: gather offsets and transform factors are computed once per POSITION, global
+  // loads and the W DMA use scalar base + 32-bit lane offset addressing, LDS addresses are immediates.
+  unsigned o[4];        // byte offsets of the four source pixels of the current position (+ this lane's granule)
+  float g[4];           // their B^T factors (0 for a pixel outside the image: zero padding)
+  auto set_pos = [&](int xi, int nu) {      // xi uniform (loop counter), nu compile-time in the loop
     // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
-    const int ya = xi == 0 ? yo[0] : yo[1], yb = xi == 3 ? yo[3] : yo[2];
-    const int xa = nu == 0 ? xo[0] : xo[1], xb = nu == 3 ? xo[3] : xo[2];
+    const int ya = Ysrc[(xi == 0 ? 0 : 1) * 512 + tid], yb = Ysrc[(xi == 3 ? 3 : 2) * 512 + tid];
+    const int xa = Xsrc[(nu == 0 ? 0 : 1) * 512 + tid], xb = Xsrc[(nu == 3 ? 3 : 2) * 512 + tid];
     const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = yb < 0 ? 0.f : ((xi == 0 || xi == 3) ? -1.f : 1.f);
     const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = xb < 0 ? 0.f : ((nu == 0 || nu == 3) ? -1.f : 1.f);
-    const f32x4 v = (r[0] * sxa + r[1] * sxb) * sya + (r[2] * sxa + r[3] * sxb) * syb;
+    // always load from a valid (clamped) address; the padding zero is applied through the factor
+    const unsigned ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
+    o[0] = ya_c + xa_c; o[1] = ya_c + xb_c; o[2] = yb_c + xa_c; o[3] = yb_c + xb_c;
+    g[0] = sxa * sya; g[1] = sxb * sya; g[2] = sxa * syb; g[3] = sxb * syb;
+  };
+  const unsigned vec_off = (unsigned)bimg * 384u + lane_coff;     // per-image vector source (NCHK == 6 only)
+  // raw granules of one iteration (chunk = it % NCHK, position already selected by set_pos)
+  auto load_x1 = [&](int chunk, f32x4 (&r)[4], int i) {      // granule i (0..3): one vector-memory instruction
+    const bool second = NCHK == 6 && chunk >= 3;
+    const char* base = (const char*)(second ? p.src1 : p.src) + (second ? chunk - 3 : chunk) * 128;
+    // spatially constant second source (pooled style vector): one value per image, still zero padded
+    if (second && p.src1_vec) r[i] = *(const f32x4*)(base + (size_t)vec_off);
+    else r[i] = *(const f32x4*)(base + (size_t)o[i]);
+  };
+  auto load_x = [&](int chunk, f32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_x1(chunk, r, i);
+  };
+  auto write_x = [&](int buf, const f32x4 (&r)[4]) {
+    const f32x4 v = r[0] * g[0] + r[1] * g[1] + r[2] * g[2] + r[3] * g[3];
     *(f32x4*)(Xb + buf * XB + srow * 128 + ps * 16) = v;
   };
-  auto dma_w = [&](int it, int buf) {
-    const float* wsrc = p.upk + (size_t)it * 192 * 32 + lane * 4;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int rbk = j * 8 + w;
-      glds16(wsrc + rbk * 256, lds_w + buf * WB + rbk * 1024);
-    }
+  auto dma_w = [&](int it, int buf, int j) {      // piece j (0..2) of this wave's share of the W tile
+    const int rbk = j * 8 + w;
+    glds16_s(p.upk + (size_t)it * 192 * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WB + rbk * 1024);
   };
 
-  f32x4 af[2][3], ag[2][3];            // position accumulators, two static sets (positions alternate between them)
+  f32x4 af[3], ag[3];                  // position accumulators (feature / gate tiles)
   f32x4 of[2][2][3], og[2][2][3];      // output accumulators (a, b, tile)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    af[0][j] = ag[0][j] = af[1][j] = ag[1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    af[j] = ag[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) of[a][b][j] = og[a][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  // fold a finished position accumulator set: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1]
-  auto fold = [&](f32x4 (&pf)[3], f32x4 (&pg)[3], int pos) {
-    const int xi = pos >> 2, nu = pos & 3;
-    const float ay0 = xi < 3 ? 1.f : 0.f, ay1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
-    const float ax0 = nu < 3 ? 1.f : 0.f, ax1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
-    const float c00 = ay0 * ax0, c01 = ay0 * ax1, c10 = ay1 * ax0, c11 = ay1 * ax1;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      of[0][0][j] += pf[j] * c00; of[0][1][j] += pf[j] * c01;
-      of[1][0][j] += pf[j] * c10; of[1][1][j] += pf[j] * c11;
-      og[0][0][j] += pg[j] * c00; og[0][1][j] += pg[j] * c01;
-      og[1][0][j] += pg[j] * c10; og[1][1][j] += pg[j] * c11;
-      pf[j] = pg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // fold the finished position accumulators: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1].
+  // nu is compile-time (zero terms are not generated: 12 of 16 remain), the row factor At[a][xi] is a uniform float.
+  // (fp32 MFMA and VALU do not overlap on a SIMD, so there is nothing to gain from a second accumulator set that
+  // would let the fold run "under" the next position's MFMAs; one set saves 24 registers.)
+  auto fold = [&](const f32x4 (&pf)[3], const f32x4 (&pg)[3], int xi, int nu, int j) {     // channel tile j
+    int by0 = xi < 3 ? 0x3f800000 : 0, by1 = xi == 0 ? 0 : (xi == 1 ? 0x3f800000 : (int)0xbf800000);
+    asm volatile("" : "+s"(by0), "+s"(by1));      // keep them scalar operands of v_pk_fma (no per-value code paths)
+    const float ay0 = __int_as_float(by0), ay1 = __int_as_float(by1);
+    if (nu < 3) {                       // At[0][nu] = 1
+      of[0][0][j] += pf[j] * ay0; og[0][0][j] += pg[j] * ay0;
+      of[1][0][j] += pf[j] * ay1; og[1][0][j] += pg[j] * ay1;
     }
+    if (nu == 1) {                      // At[1][nu] = 1
+      of[0][1][j] += pf[j] * ay0; og[0][1][j] += pg[j] * ay0;
+      of[1][1][j] += pf[j] * ay1; og[1][1][j] += pg[j] * ay1;
+    } else if (nu >= 2) {               // At[1][nu] = -1
+      of[0][1][j] -= pf[j] * ay0; og[0][1][j] -= pg[j] * ay0;
+      of[1][1][j] -= pf[j] * ay1; og[1][1][j] -= pg[j] * ay1;
+    }
+    // pin the sums here: in unrolled code hipcc would otherwise sink every fold to the end of the kernel and keep
+    // all 16 position results alive (in scratch) until then
+    asm volatile("" : "+v"(of[0][0][j]), "+v"(of[0][1][j]), "+v"(of[1][0][j]), "+v"(of[1][1][j]),
+                      "+v"(og[0][0][j]), "+v"(og[0][1][j]), "+v"(og[1][0][j]), "+v"(og[1][1][j]));
   };
 
+  // ---- pipeline.  Three-slot ring of LDS tiles; one workgroup barrier per iteration.  During iteration `it`:
+  //   * the W tile of it+2 is DMA'd into slot (it+2)%3 (free since the barrier that ended it-1) and the X tile of
+  //     it+2 is transformed into the same slot from the granules loaded an iteration ago;
+  //   * the raw granules of it+3 are fetched into registers;
+  //   * the k-half 0 fragments of it+1 are read before the barrier (slot published by the previous barrier), so the
+  //     MFMA stream continues straight across it.
+  // The DMA of this iteration is complete (vmcnt leaves only the 4 younger granule loads outstanding) before the
+  // barrier that publishes the slot.  No scratch (spill) access may sit between the DMA and that wait.
+  auto end_barrier = [&](bool loads_in_flight) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (loads_in_flight) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   f32x4 r[4];
-  load_x(0, r);
-  dma_w(0, 0);
-  write_x(0, 0, r);
+  set_pos(0, 0);
+#pragma unroll
+  for (int i0 = 0; i0 < 2; ++i0) {     // ring slots 0 and 1 (chunks 0, 1 of position 0)
+    load_x(i0, r);
+    dma_w(i0, i0, 0);
+    dma_w(i0, i0, 1);
+    dma_w(i0, i0, 2);
+    write_x(i0, r);
+  }
+  load_x(2, r);                        // granules of iteration 2 (chunk 2 of position 0)
   dma_wait_all();
   __syncthreads();
-  for (int pp = 0; pp < 8; ++pp) {               // position pairs; body unrolled so the accumulator sets are static
+  f32x4 wf[3], wg[3], xh;              // k-half 0 fragments of the current iteration (read one iteration ahead)
+  xh = *(const f32x4*)(Xb + tg * 2048 + off0);
 #pragma unroll
-    for (int k = 0; k < 2 * NCHK; ++k) {
-      const int it = pp * 2 * NCHK + k;
-      const int set = k / NCHK, chunk = k % NCHK;      // compile-time
-      const int pos = pp * 2 + set;
-      const int buf = k & 1;                     // == it & 1
-      const char* Xt = Xb + buf * XB + tg * 2048;
-      const char* Wf = Wb + buf * WB + (3 * chh) * 2048;
-      const char* Wg = Wb + buf * WB + (6 + 3 * chh) * 2048;
-      f32x4 wf[3], wg[3], xh;
+  for (int j = 0; j < 3; ++j) {
+    wf[j] = *(const f32x4*)(Wb + (3 * chh + j) * 2048 + off0);
+    wg[j] = *(const f32x4*)(Wb + (6 + 3 * chh + j) * 2048 + off0);
+  }
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) {               // rows of the 4x4 position grid; body unrolled: nu, the chunk, the
+#pragma unroll                                   // accumulator set and the ring slots are compile-time
+    for (int k = 0; k < 4 * NCHK; ++k) {
+      const int it = xi * 4 * NCHK + k;
+      const int nu = k / NCHK, chunk = k % NCHK;
+      const int b0 = k % 3, b1 = (k + 1) % 3, b2 = (k + 2) % 3;     // == (it + i) % 3: 4*NCHK is a multiple of 3
+      const char* Xt = Xb + b0 * XB + tg * 2048;
+      const char* Wf = Wb + b0 * WB + (3 * chh) * 2048;
+      const char* Wg = Wb + b0 * WB + (6 + 3 * chh) * 2048;
+      const bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
       WINO_STAMP(0);
-      // ---- k-half 0: 7 fragment reads, first 6 MFMAs
-      xh = *(const f32x4*)(Xt + off0);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        wf[j] = *(const f32x4*)(Wf + j * 2048 + off0);
-        wg[j] = *(const f32x4*)(Wg + j * 2048 + off0);
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][0], xh[0], af[set][j], 0, 0, 0);
-        ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j][0], xh[0], ag[set][j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      WINO_STAMP(1);
-      // ---- in the shadow of the MFMA pipe: raw granules + W DMA of iteration it+1 (a whole iteration to land),
-      //      and the fold of the previous position (its MFMAs finished an iteration ago: no drain wait)
-      if (it + 1 < NIT) {
-        load_x(it + 1, r);
-        dma_w(it + 1, buf ^ 1);
-      }
-      if (chunk == 0 && it > 0) fold(af[set ^ 1], ag[set ^ 1], pos - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      WINO_STAMP(2);
-      // ---- k-half 1 fragments are fetched BEFORE the remaining 18 MFMAs of k-half 0 (both waves of a SIMD run in
-      //      lockstep, so an LDS read latency after the MFMAs would be fully exposed)
       f32x4 wf1[3], wg1[3], xh1;
-      xh1 = *(const f32x4*)(Xt + off1);
+      xh1 = *(const f32x4*)(Xt + off1);                      // k-half 1 fragments of this iteration
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         wf1[j] = *(const f32x4*)(Wf + j * 2048 + off1);
         wg1[j] = *(const f32x4*)(Wg + j * 2048 + off1);
       }
-#pragma unroll
-      for (int e = 1; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xh[e], af[set][j], 0, 0, 0);
-          ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[j][e], xh[e], ag[set][j], 0, 0, 0);
-        }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          af[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[j][e], xh1[e], af[set][j], 0, 0, 0);
-          ag[set][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg1[j][e], xh1[e], ag[set][j], 0, 0, 0);
-        }
-      WINO_STAMP(3);
-      // ---- X tile of it+1 (hipcc waits for the 4 loads; the W DMA has had the same whole iteration to land)
-      if (it + 1 < NIT) write_x(it + 1, buf ^ 1, r);
-      WINO_STAMP(4);
-      dma_wait_all();
-      WINO_STAMP(5);
-      __syncthreads();
-      WINO_STAMP(6);
       __builtin_amdgcn_sched_barrier(0);
+      auto group = [&](const f32x4 (&a)[3], const f32x4 (&b)[3], const f32x4& x, int e, bool first) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          // first k-step of a position: C = 0 (the accumulators still hold the previous position, already folded)
+          const f32x4 cf = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : af[j];
+          const f32x4 cg = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : ag[j];
+          af[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], x[e], cf, 0, 0, 0);
+          ag[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], x[e], cg, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (chunk == 0) {                      // fold the previous position (row 0, nu 0: the zero-initialised set, a no-op)
+        const int pxi = nu == 0 ? xi - 1 : xi, pnu = (nu + 3) & 3;
+        fold(af, ag, pxi, pnu, 0);
+        fold(af, ag, pxi, pnu, 1);
+        fold(af, ag, pxi, pnu, 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // The 7 vector-memory instructions of an iteration (3 W DMA pieces, 4 granule loads) are issued one per MFMA
+      // group: issued back to back by all 8 waves they fill the CU's vector-memory queue, and a wave stuck in
+      // front of a full queue cannot issue its MFMAs either.
+      group(wf, wg, xh, 0, chunk == 0);
+      WINO_STAMP(1);
+      if (more2) {
+        dma_wait_all();                    // granules of it+2 (and the DMA of it+1), issued an iteration ago
+        write_x(b2, r);
+      }
+      if ((k + 3) % NCHK == 0 && more3)    // position of the granules fetched next
+        set_pos(xi + ((k + 3) / NCHK) / 4, ((k + 3) / NCHK) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) dma_w(it + 2, b2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WINO_STAMP(2);
+      group(wf, wg, xh, 1, false);
+      if (more2) dma_w(it + 2, b2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf, wg, xh, 2, false);
+      if (more2) dma_w(it + 2, b2, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf, wg, xh, 3, false);
+      if (more3) load_x1((k + 3) % NCHK, r, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf1, wg1, xh1, 0, false);
+      if (more1) {                                          // k-half 0 fragments of it+1 (published slot)
+        const char* Xn = Xb + b1 * XB + tg * 2048;
+        xh = *(const f32x4*)(Xn + off0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          wf[j] = *(const f32x4*)(Wb + b1 * WB + (3 * chh + j) * 2048 + off0);
+          wg[j] = *(const f32x4*)(Wb + b1 * WB + (6 + 3 * chh + j) * 2048 + off0);
+        }
+      }
+      if (more3) load_x1((k + 3) % NCHK, r, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf1, wg1, xh1, 1, false);
+      if (more3) load_x1((k + 3) % NCHK, r, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf1, wg1, xh1, 2, false);
+      if (more3) load_x1((k + 3) % NCHK, r, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf1, wg1, xh1, 3, false);
+      WINO_STAMP(3);
+      end_barrier(more3);
+      WINO_STAMP(4);
     }
   }
-  fold(af[1], ag[1], 15);
+  WINO_TRACE_DUMP();
+  fold(af, ag, 3, 3, 0);
+  fold(af, ag, 3, 3, 1);
+  fold(af, ag, 3, 3, 2);
 
   // ---- epilogue: lane holds 4 consecutive channels of tile (lane&15): 2x2 output pixels
   const int q = lane >> 4;
@@ -276,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 
 template <int NCHK>
 static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 2 * 64 * 128 + 2 * 192 * 128;
+  constexpr int LDS = 3 * 64 * 128 + 3 * 192 * 128 + 8 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // three-slot ring of X and W tiles (96 KB) + source offsets
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<NCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -24,11 +24,18 @@ def build():
 
 
 def table(t, names, nstamp):
-    print("it   " + "  ".join("%-16s" % n for n in names) + "  total")
-    for it in range(6, 24):
-        d = [t[it, k + 1] - t[it, k] for k in range(nstamp - 1)]
-        print("%2d   " % it + "  ".join("%-16d" % v for v in d) + "  %d" % (t[it, nstamp - 1] - t[it, 0]))
-    print("iterations 0..46: %d cycles, mean per iteration %.0f" % (t[46, nstamp - 1] - t[0, 0], (t[46, nstamp - 1] - t[0, 0]) / 47.0))
+    """t: [2 waves][48 iterations][8 stamps]; prints both waves' phase durations and their start offset."""
+    t0 = t[0, 0, 0]
+    print("it   " + "  ".join("%-9s" % n for n in names) + " total | wave 4: start " + "  ".join("%-9s" % n for n in names) + " total")
+    for it in range(48):
+        row = "%2d   " % it
+        for wv in range(2):
+            d = [t[wv, it, k + 1] - t[wv, it, k] for k in range(nstamp - 1)]
+            if wv == 1:
+                row += " |         %6d " % (t[1, it, 0] - t0)
+            row += "  ".join("%-9d" % v for v in d) + " %5d" % (t[wv, it, nstamp - 1] - t[wv, it, 0])
+        print(row)
+    print("iterations 0..46: %d cycles, mean per iteration %.0f" % (t[0, 46, nstamp - 1] - t[0, 0, 0], (t[0, 46, nstamp - 1] - t[0, 0, 0]) / 47.0))
 
 
 def run():
@@ -43,15 +50,15 @@ def run():
     b = synth.uniform(1, "t.b", (192,), -0.1, 0.1)
     x = torch.from_numpy(synth.uniform(1, "t.x", (32, 96, 64, 64), -1, 1)).cuda()
     lib = ctypes.CDLL(SO)
-    buf = (ctypes.c_ulonglong * (48 * 8))()
+    buf = (ctypes.c_ulonglong * (96 * 8))()
     eng = Engine(0)
     for _ in range(3):
         eng.gated_conv2d(x, w, b)
     torch.cuda.synchronize()
     assert lib.se_debug_wino_trace(buf) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(48, 8).astype(np.int64)
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 48, 8).astype(np.int64)
     print("== wino_kernel (se_wino.hip)")
-    table(t, ["frag+6mfma", "shadow ld/dma", "42 mfma", "x-write", "dma-wait", "barrier"], 7)
+    table(t, ["6mfma", "xwrite+ld", "42mfma", "barrier"], 5)
 
 
 if __name__ == "__main__":
