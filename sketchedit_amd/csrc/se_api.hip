@@ -344,7 +344,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   p.C0 = C0; p.C1 = C1 ? C1 : C0; p.C0g = C0 / 4; p.CG = L.CGp;
   const int KW = d.up ? 2 : d.k;
   p.T = L.T; p.KW = KW; p.stride = d.stride; p.dil = d.rate; p.pad = pad;
-  p.magicCG = (65536 + L.CGp - 1) / L.CGp; p.magicKW = 256 / KW + 1;
+  p.magicCG = (65536 + L.CGp - 1) / L.CGp; p.magicKW = 256 / KW + 1; p.magicKH = L.T / KW;
   for (int gi = 0; gi < L.nch * 8 + 8; ++gi)
     if (((gi * p.magicCG) >> 16) != gi / L.CGp) return fail(c, "layer %s: magic division check failed", d.name);
   for (int t = 0; t <= L.T + 8; ++t)

@@ -40,6 +40,29 @@ DEVFN void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
       : "v"(voff), "s"(sbase), "s"(lds_addr)
       : "memory");
 }
+// LDS-DMA through a buffer resource: lanes whose byte offset is outside [0, num_records) deliver ZEROS to LDS
+// (hardware range check), which is how zero padding is staged without a zero page or a pointer select.
+typedef int se_i32x4 __attribute__((ext_vector_type(4)));
+DEVFN se_i32x4 make_rsrc(const void* base, unsigned bytes) {
+  se_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32));     // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;                                                    // 32-bit data format (gfx9 family)
+  return r;
+}
+DEVFN void bufdma16(unsigned voff, se_i32x4 rsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
 DEVFN void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 DEVFN unsigned lds_addr_of(const void* p) {
@@ -85,10 +108,12 @@ DEVFN void mfma_chunk(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const c
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 wa = wn;
       if (nt + 1 < NT) wn = *(const f32x4*)(Wt + (nt + 1) * 2048 + off);   // fragment prefetch, one tile ahead
+      // k-step outer, pixel tile inner: consecutive MFMAs never share an accumulator (a dependent
+      // v_mfma_f32_16x16x4_f32 issues after 40 cycles instead of 32 when the wave has the pipe to itself)
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
+      for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int pt = 0; pt < PT; ++pt)
           acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], xb[pt][r], acc[nt][pt], 0, 0, 0);
       }
     }

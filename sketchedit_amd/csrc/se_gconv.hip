@@ -19,7 +19,13 @@
 
 namespace se {
 
-template <int NT, int PT, bool MIXED, int WPS>
+// FAST: single-source layers (everything but the concat fallbacks).  fp32 MFMA and VALU share a SIMD's issue time
+// (se_wino.hip), and the generic gather spends ~17 VALU instructions per staged granule on bounds tests, 64-bit
+// addresses and the zero-page select -- as much SIMD time as the MFMAs of the narrow (N48/N24) layers.  The fast
+// path stages through a buffer resource: per pixel row it keeps one byte offset and one tap-validity bit mask
+// (built once per workgroup), so a granule costs 3 VALU (bit extract, add, or) and an out-of-image tap is simply an
+// out-of-range offset, for which the hardware delivers zeros.
+template <int NT, int PT, bool MIXED, int WPS, bool FAST>
 __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   constexpr int PIX = PT * 64;
   constexpr int NP = NT * 16;
@@ -53,11 +59,22 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   }
   __syncthreads();
   int rb[NX], ryx[NX];
+  unsigned pixoff[NX], inv[NX];     // FAST: byte offset of the row's tap-(0,0) pixel before padding; ~tap validity mask
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int2 e = rowtab[(i * 4 + w) * 8 + (lane >> 3)];
     rb[i] = e.x;
     ryx[i] = e.y;
+    if (FAST) {
+      const int y0 = e.y >> 16, x0 = e.y & 0xffff;       // invalid rows: y0 = 16384, every tap fails the row test
+      pixoff[i] = (unsigned)((e.x * p.Hin + y0) * p.Win + x0) * (unsigned)(p.C0 * 4);
+      const int KH = p.magicKH;
+      unsigned colbits = 0, mask = 0;
+      for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(x0 + kx * p.dil - padx) < (unsigned)p.Wlim ? 1u : 0u) << kx;
+      for (int ky = 0; ky < KH; ++ky)
+        if ((unsigned)(y0 + ky * p.dil - pady) < (unsigned)p.Hlim) mask |= colbits << (ky * p.KW);
+      inv[i] = ~mask;                                     // bits >= T stay set: K padding reads zeros
+    }
   }
   __syncthreads();
 
@@ -67,7 +84,30 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   frag_offsets(lane, off0, off1);
   const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
 
-  auto stage = [&](int ch, int buf) {
+  const se_i32x4 rsrc = make_rsrc(p.src0, (unsigned)p.B * p.Hin * p.Win * p.C0 * 4u);
+  auto stage_fast = [&](int ch, int buf) {
+    const int gi = ch * 8 + s_log;
+    int tap = __umul24(gi, p.magicCG) >> 16;
+    const int cg = gi - __umul24(tap, p.CG);
+    const int ky = __umul24(tap, p.magicKW) >> 8, kx = tap - __umul24(ky, p.KW);
+    const int dy = __mul24(ky, p.dil) - pady, dx = __mul24(kx, p.dil) - padx;
+    const unsigned delta = (unsigned)(__mul24(__mul24(dy, p.Win) + dx, p.C0 * 4) + cg * 16);
+    tap = min(tap, 31);
+    const unsigned xdst = lds_x + buf * XBYTES;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)inv[i], tap, 1);      // all ones if the tap is outside
+      bufdma16((pixoff[i] + delta) | m, rsrc, xdst + (i * 4 + w) * 1024);
+    }
+    const unsigned wdst = lds_w + buf * WBYTES;
+    const float* wsrc = wbase + (size_t)ch * NP * 32;
+#pragma unroll
+    for (int j = 0; j < (NT * 2 + 3) / 4; ++j) {
+      const int rbk = j * 4 + w;
+      if (rbk < NT * 2) glds16_s(wsrc + rbk * 256, (unsigned)lane * 16u, wdst + rbk * 1024);
+    }
+  };
+  auto stage_any = [&](int ch, int buf) {
     // which granule of the flattened K axis this lane fetches: (tap, 4-channel group)
     const int gi = ch * 8 + s_log;
     const int tap = (gi * p.magicCG) >> 16, cg = gi - tap * p.CG;
@@ -98,6 +138,10 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       const int rbk = j * 4 + w;
       if (rbk < NT * 2) glds16(wsrc + rbk * 256, wdst + rbk * 1024);
     }
+  };
+  auto stage = [&](int ch, int buf) {
+    if (FAST) stage_fast(ch, buf);
+    else stage_any(ch, buf);
   };
 
   f32x4 acc[NT][PT];
@@ -172,22 +216,34 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   }
 }
 
-template <int NT, int PT, bool MIXED, int WPS>
-static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label) {
+template <int NT, int PT, bool MIXED, int WPS, bool FAST>
+static hipError_t launch_gconv_f(const GConvParams& p, hipStream_t st, int label) {
   constexpr int PIX = PT * 64;
   constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128;
   static_assert(PIX * 8 <= 2 * PIX * 128, "row table aliases the X buffers");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gconv_kernel<NT, PT, MIXED, WPS>,
+    hipError_t e = hipFuncSetAttribute((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int grid = (p.total_pix + PIX - 1) / PIX;
   ProfScope ps_(st, label);
-  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS>), dim3(grid, p.up2 ? 4 : 1), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST>), dim3(grid, p.up2 ? 4 : 1), dim3(256), LDS, st, p);
   return hipGetLastError();
+}
+
+// the buffer-resource fast path needs one source, <= 31 taps and a source below 2 GiB (32-bit byte offsets)
+static bool fast_eligible(const GConvParams& p) {
+  static const bool enabled = !(getenv("SE_GCONV_FAST") && atoi(getenv("SE_GCONV_FAST")) == 0);
+  return enabled && p.C0g == p.CG && !p.ushift && p.T <= 31 && p.magicKH * p.KW == p.T &&
+         (long long)p.B * p.Hin * p.Win * p.C0 * 4 < (1ll << 31);
+}
+template <int NT, int PT, bool MIXED, int WPS>
+static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label) {
+  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true>(p, st, label)
+                          : launch_gconv_f<NT, PT, MIXED, WPS, false>(p, st, label);
 }
 
 // Tile shapes.  variant 0 is the default; SE_GCONV_VARIANT_<cfg>=k (environment) selects another one for

@@ -44,6 +44,7 @@ struct GConvParams {
   int C0g, CG;         // granules (4 floats) per tap in src0 / in total
   int T, KW;           // taps, taps per kernel row
   int magicCG, magicKW; // x/CG == (x*magicCG)>>16, t/KW == (t*magicKW)>>8 on the ranges used (host-verified)
+  int magicKH;          // kernel rows T / KW
   int stride, dil, pad;
   int ushift;          // 1: source is read through a nearest x2 upsample (coords >> 1)
   int up2;             // 1: sub-pixel form of nearest-x2 + 3x3: blockIdx.y = output parity class (py,px), a 2x2 conv
