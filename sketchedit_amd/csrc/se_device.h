@@ -94,9 +94,12 @@ DEVFN int xcd_tile(int bid, int nblocks) {
 // Wt: [NT*16][128 B] tile, Xt: this wave's [PT*16][128 B] tile, both with the 16-B slot of row r
 // stored at (slot ^ ((r>>1)&7)).  off0/off1 = per-lane byte offsets for k-half 0/1.
 // v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D[i=(lane>>4)*4+reg][j=lane&15].
-template <int NT, int PT>
+struct NoHook { DEVFN void operator()(int) const {} };
+// hook(slot), slot = 0 .. 2*NT-1, is called after the MFMAs of every (k-half, channel tile) step: the caller issues the
+// staging DMA of the next chunk there, one piece per step, instead of as one burst in front of the MFMAs.
+template <int NT, int PT, typename Hook = NoHook>
 DEVFN void mfma_chunk(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const char* __restrict__ Xt, int off0,
-                      int off1) {
+                      int off1, Hook hook = Hook()) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int off = half ? off1 : off0;
@@ -116,6 +119,7 @@ DEVFN void mfma_chunk(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const c
         for (int pt = 0; pt < PT; ++pt)
           acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], xb[pt][r], acc[nt][pt], 0, 0, 0);
       }
+      hook(half * NT + nt);
     }
   }
 }

@@ -85,27 +85,35 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
 
   const se_i32x4 rsrc = make_rsrc(p.src0, (unsigned)p.B * p.Hin * p.Win * p.C0 * 4u);
-  auto stage_fast = [&](int ch, int buf) {
+  // fast path staging, split so that the pieces can be issued one per MFMA step (mfma_chunk hook): a burst of
+  // vector-memory instructions fills the CU's queue and stalls the wave (and its MFMAs) in front of it
+  constexpr int NWP = (NT * 2 + 3) / 4;          // W staging pieces per wave
+  constexpr int NPIECE = NX + NWP;
+  int f_tap = 0;
+  unsigned f_delta = 0;
+  auto fast_head = [&](int ch) {
     const int gi = ch * 8 + s_log;
     int tap = __umul24(gi, p.magicCG) >> 16;
     const int cg = gi - __umul24(tap, p.CG);
     const int ky = __umul24(tap, p.magicKW) >> 8, kx = tap - __umul24(ky, p.KW);
     const int dy = __mul24(ky, p.dil) - pady, dx = __mul24(kx, p.dil) - padx;
-    const unsigned delta = (unsigned)(__mul24(__mul24(dy, p.Win) + dx, p.C0 * 4) + cg * 16);
-    tap = min(tap, 31);
-    const unsigned xdst = lds_x + buf * XBYTES;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)inv[i], tap, 1);      // all ones if the tap is outside
-      bufdma16((pixoff[i] + delta) | m, rsrc, xdst + (i * 4 + w) * 1024);
+    f_delta = (unsigned)(__mul24(__mul24(dy, p.Win) + dx, p.C0 * 4) + cg * 16);
+    f_tap = min(tap, 31);
+  };
+  auto fast_piece = [&](int ch, int buf, int q) {      // q compile-time after unrolling
+    if (q < NX) {
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)inv[q], f_tap, 1);      // all ones if the tap is outside
+      bufdma16((pixoff[q] + f_delta) | m, rsrc, lds_x + buf * XBYTES + (q * 4 + w) * 1024);
+    } else if (q < NPIECE) {
+      const int rbk = (q - NX) * 4 + w;
+      if (rbk < NT * 2)
+        glds16_s(wbase + (size_t)ch * NP * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WBYTES + rbk * 1024);
     }
-    const unsigned wdst = lds_w + buf * WBYTES;
-    const float* wsrc = wbase + (size_t)ch * NP * 32;
+  };
+  auto stage_fast = [&](int ch, int buf) {
+    fast_head(ch);
 #pragma unroll
-    for (int j = 0; j < (NT * 2 + 3) / 4; ++j) {
-      const int rbk = j * 4 + w;
-      if (rbk < NT * 2) glds16_s(wsrc + rbk * 256, (unsigned)lane * 16u, wdst + rbk * 1024);
-    }
+    for (int q = 0; q < NPIECE; ++q) fast_piece(ch, buf, q);
   };
   auto stage_any = [&](int ch, int buf) {
     // which granule of the flattened K axis this lane fetches: (tap, 4-channel group)
@@ -155,8 +163,21 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   __syncthreads();
   for (int ch = 0; ch < p.nch; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < p.nch) stage(ch + 1, buf ^ 1);                 // DMA of the next chunk flies under the MFMAs
-    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    if (FAST) {
+      // DMA of the next chunk flies under the MFMAs, one piece per MFMA step
+      const bool more = ch + 1 < p.nch;
+      if (more) fast_head(ch + 1);
+      constexpr int SLOTS = 2 * NT, PER = (NPIECE + SLOTS - 1) / SLOTS;
+      mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, [&](int slot) {
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) fast_piece(ch + 1, buf ^ 1, slot * PER + u);
+        }
+      });
+    } else {
+      if (ch + 1 < p.nch) stage(ch + 1, buf ^ 1);               // DMA of the next chunk flies under the MFMAs
+      mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    }
     dma_wait_all();
     __syncthreads();
   }
