@@ -146,8 +146,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
     const bool second = NCHK == 6 && chunk >= 3;
     const char* base = (const char*)(second ? p.src1 : p.src) + (second ? chunk - 3 : chunk) * 128;
     // spatially constant second source (pooled style vector): one value per image, still zero padded
-    if (second && p.src1_vec) r[i] = *(const f32x4*)(base + (size_t)vec_off);
-    else r[i] = *(const f32x4*)(base + (size_t)o[i]);
+    if (second && p.src1_vec) gload16(r[i], vec_off, base);
+    else gload16(r[i], o[i], base);
   };
   auto load_x = [&](int chunk, f32x4 (&r)[4]) {
 #pragma unroll
@@ -205,9 +205,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   //     MFMA stream continues straight across it.
   // The DMA of this iteration is complete (vmcnt leaves only the 4 younger granule loads outstanding) before the
   // barrier that publishes the slot.  No scratch (spill) access may sit between the DMA and that wait.
+  // (The two-source instantiation spills a few LDS base addresses inside the loop; scratch traffic is vector memory
+  // too and would break the exact counts, so it waits with vmcnt(0) instead.)
+  constexpr bool EXACT = NCHK == 3;
   auto end_barrier = [&](bool loads_in_flight) {
     __builtin_amdgcn_sched_barrier(0);
-    if (loads_in_flight) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (EXACT && loads_in_flight) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
     dma_w(i0, i0, 0);
     dma_w(i0, i0, 1);
     dma_w(i0, i0, 2);
+    wait_loaded<0>(r);
     write_x(i0, r);
   }
   load_x(2, r);                        // granules of iteration 2 (chunk 2 of position 0)
@@ -271,19 +275,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       }
       // The 7 vector-memory instructions of an iteration (3 W DMA pieces, 4 granule loads) are issued one per MFMA
       // group: issued back to back by all 8 waves they fill the CU's vector-memory queue, and a wave stuck in
-      // front of a full queue cannot issue its MFMAs either.
+      // front of a full queue cannot issue its MFMAs either.  The granules are consumed a full iteration after
+      // their loads were issued (vmcnt(3): everything but this iteration's three DMA pieces has landed).
       group(wf, wg, xh, 0, chunk == 0);
-      WINO_STAMP(1);
-      if (more2) {
-        dma_wait_all();                    // granules of it+2 (and the DMA of it+1), issued an iteration ago
-        write_x(b2, r);
-      }
-      if ((k + 3) % NCHK == 0 && more3)    // position of the granules fetched next
-        set_pos(xi + ((k + 3) / NCHK) / 4, ((k + 3) / NCHK) & 3);
-      __builtin_amdgcn_sched_barrier(0);
       if (more2) dma_w(it + 2, b2, 0);
       __builtin_amdgcn_sched_barrier(0);
-      WINO_STAMP(2);
+      WINO_STAMP(1);
       group(wf, wg, xh, 1, false);
       if (more2) dma_w(it + 2, b2, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -291,9 +288,6 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       if (more2) dma_w(it + 2, b2, 2);
       __builtin_amdgcn_sched_barrier(0);
       group(wf, wg, xh, 3, false);
-      if (more3) load_x1((k + 3) % NCHK, r, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      group(wf1, wg1, xh1, 0, false);
       if (more1) {                                          // k-half 0 fragments of it+1 (published slot)
         const char* Xn = Xb + b1 * XB + tg * 2048;
         xh = *(const f32x4*)(Xn + off0);
@@ -303,15 +297,27 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
           wg[j] = *(const f32x4*)(Wb + b1 * WB + (6 + 3 * chh + j) * 2048 + off0);
         }
       }
-      if (more3) load_x1((k + 3) % NCHK, r, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      group(wf1, wg1, xh1, 0, false);
+      WINO_STAMP(2);
+      if (more2) {
+        wait_loaded<EXACT ? 3 : 0>(r);     // granules of it+2, issued an iteration ago
+        write_x(b2, r);
+      }
+      if ((k + 3) % NCHK == 0 && more3)    // position of the granules fetched next
+        set_pos(xi + ((k + 3) / NCHK) / 4, ((k + 3) / NCHK) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more3) load_x1((k + 3) % NCHK, r, 0);
       __builtin_amdgcn_sched_barrier(0);
       group(wf1, wg1, xh1, 1, false);
-      if (more3) load_x1((k + 3) % NCHK, r, 2);
+      if (more3) load_x1((k + 3) % NCHK, r, 1);
       __builtin_amdgcn_sched_barrier(0);
       group(wf1, wg1, xh1, 2, false);
-      if (more3) load_x1((k + 3) % NCHK, r, 3);
+      if (more3) load_x1((k + 3) % NCHK, r, 2);
       __builtin_amdgcn_sched_barrier(0);
       group(wf1, wg1, xh1, 3, false);
+      if (more3) load_x1((k + 3) % NCHK, r, 3);
+      __builtin_amdgcn_sched_barrier(0);
       WINO_STAMP(3);
       end_barrier(more3);
       WINO_STAMP(4);

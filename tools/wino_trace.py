@@ -58,7 +58,7 @@ def run():
     assert lib.se_debug_wino_trace(buf) == 0
     t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 48, 8).astype(np.int64)
     print("== wino_kernel (se_wino.hip)")
-    table(t, ["6mfma", "xwrite+ld", "42mfma", "barrier"], 5)
+    table(t, ["6mfma", "24mfma", "xw+18mfma", "barrier"], 5)
 
 
 if __name__ == "__main__":
