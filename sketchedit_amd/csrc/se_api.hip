@@ -71,6 +71,7 @@ struct Layer {
   float* d_w = nullptr;
   float* d_b = nullptr;
   float* d_u = nullptr;       // Winograd-transformed weights (eligible layers only)
+  float* d_ub = nullptr;      // bias in the row order of the 48 -> 96 Winograd kernel (MIXED tiles)
 };
 
 // ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
@@ -155,6 +156,8 @@ int fail(se_ctx* c, const char* fmt, ...) {
 // cin_map[pc] = checkpoint input channel of packed channel pc, or -1 for zero padding.
 bool wino_eligible_layer(const LayerDef& d);
 int pack_wino(se_ctx* c, Layer& L);
+bool wino48_eligible_layer(const LayerDef& d);
+int pack_wino48(se_ctx* c, Layer& L);
 
 int xcd_remap_enabled() {      // SE_XCD_REMAP=0 switches the XCD-aware tile order off (A/B measurements)
   static const int v = getenv("SE_XCD_REMAP") ? atoi(getenv("SE_XCD_REMAP")) : 1;
@@ -237,6 +240,7 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   L.cfg = cfg; L.NP = NP; L.nch = nch; L.G = G; L.CGp = Cp / 4; L.T = T;
   L.packed = true;
   if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
+  if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
   return 0;
 }
 
@@ -270,6 +274,46 @@ int pack_wino(se_ctx* c, Layer& L) {
   if (L.d_u) (void)hipFree(L.d_u);
   HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
   HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// 48 -> 96 layers (se_wino48.hip): 24 iterations = 8 position pairs x 3 chunks; chunk c of pair pp holds in its
+// k-half h the 16-channel group ((2c+h) % 3) of position 2pp + ((2c+h) >= 3).  Rows in the MIXED order: tile t =
+// features 8t..8t+7, then their gates.
+bool wino48_eligible_layer(const LayerDef& d) {
+  return d.k == 3 && d.stride == 1 && !d.up && d.cin == 48 && d.cout == 96 && d.act != ACT_NONE;
+}
+int pack_wino48(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int NP = 96;
+  std::vector<float> img((size_t)24 * NP * 32, 0.f), bias(NP, 0.f);
+  for (int n = 0; n < NP; ++n) {
+    const int t = n / 16, r = n % 16;
+    const int oc = r < 8 ? t * 8 + r : 48 + t * 8 + (r - 8);
+    bias[n] = L.b[oc];
+    for (int ic = 0; ic < 48; ++ic) {
+      const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
+      float tt[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int kx = 0; kx < 3; ++kx) tt[i][kx] = Gm[i][0] * g[kx] + Gm[i][1] * g[3 + kx] + Gm[i][2] * g[6 + kx];
+      for (int pos = 0; pos < 16; ++pos) {
+        const int xi = pos >> 2, nu = pos & 3;
+        const float u = tt[xi][0] * Gm[nu][0] + tt[xi][1] * Gm[nu][1] + tt[xi][2] * Gm[nu][2];
+        const int pp = pos >> 1, u6 = (pos & 1) * 3 + ic / 16;        // index of the 16-channel group in the pair
+        const int it = pp * 3 + u6 / 2, kin = (u6 % 2) * 16 + ic % 16;
+        const int s_ = kin / 4, e = kin % 4;
+        const int ps = s_ ^ ((n >> 1) & 7);
+        img[((size_t)it * NP + n) * 32 + ps * 4 + e] = u;
+      }
+    }
+  }
+  if (L.d_u) (void)hipFree(L.d_u);
+  if (L.d_ub) (void)hipFree(L.d_ub);
+  HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_ub, bias.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_ub, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -334,6 +378,19 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
     set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name);
     HIPCHK(c, launch_wino(wp, c->st));
+    return 0;
+  }
+  static const bool use_wino48 = !(getenv("SE_WINOGRAD48") && atoi(getenv("SE_WINOGRAD48")) == 0);
+  if (use_wino && use_wino48 && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && (long long)B * Hin * Win * 192 < (1ll << 31) &&
+      (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+    WinoParams wp;
+    memset(&wp, 0, sizeof wp);
+    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst; wp.zeros = c->zeros;
+    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
+    wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+    wp.xcd = xcd_remap_enabled();
+    set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 48, d.name);
+    HIPCHK(c, launch_wino48(wp, c->st));
     return 0;
   }
   GConvParams p;
@@ -592,6 +649,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_w) (void)hipFree(kv.second.d_w);
       if (kv.second.d_b) (void)hipFree(kv.second.d_b);
       if (kv.second.d_u) (void)hipFree(kv.second.d_u);
+      if (kv.second.d_ub) (void)hipFree(kv.second.d_ub);
     }
   if (c->zeros) (void)hipFree(c->zeros);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
@@ -815,6 +873,7 @@ int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host
   if (L.d_w) (void)hipFree(L.d_w);
   if (L.d_b) (void)hipFree(L.d_b);
   if (L.d_u) (void)hipFree(L.d_u);
+  if (L.d_ub) (void)hipFree(L.d_ub);
   return rc;
 }
 

@@ -1,0 +1,297 @@
+// Winograd F(2x2,3x3) form of the 3x3 stride-1 gated convolution 48 -> 96 (conv3, conv14, xconv3, pmconv3,
+// allconv14, wconv3, conv_mask_14 of /root/reference/models/networks/editline_g.py:44-47,87-90 and
+// editline2_g.py:20-21: the 128x128 level of every encoder / decoder).  Same math, transform matrices, tile
+// geometry (dilation through the polyphase sub-images) and pipeline as se_wino.hip -- read that header first.
+// What differs:
+//   * K per position is 48, i.e. 1.5 chunks of 32.  Two consecutive positions (P0, P1) share three chunks:
+//         chunk A = [P0 ch 0-15 | P0 ch 16-31]   chunk B = [P0 ch 32-47 | P1 ch 0-15]   chunk C = [P1 ch 16-31 | P1 ch 32-47]
+//     so no MFMA k-step is spent on padding; in chunk B the two k-halves accumulate into different positions
+//     (P0 is folded between them).  24 iterations instead of 48.
+//   * 96 packed rows in the MIXED order (8 features + their 8 gates per 16-row tile, gate exchange by a lane
+//     swap in the epilogue), so a wave owns 3 row tiles x 32 tiles: 5 LDS fragment reads per 24 MFMAs (7 in
+//     se_wino.hip) and the same 24 + 96 accumulator registers.
+//   * One workgroup = 8 waves = 128 tiles; a lane stages TWO granules per iteration (same tile and slot in both
+//     k-halves), from two (offset, factor) sets: one for the even, one for the odd position of the pair.
+#include "se_device.h"
+
+#include <cstdlib>
+
+namespace se {
+
+__global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
+  constexpr int TILES = 128;
+  constexpr int XB = TILES * 128, WB = 96 * 128;
+  constexpr int NIT = 24;              // 8 position pairs x 3 chunks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  char* Wb = smem + 3 * XB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chh = w & 1, tp = w >> 1;          // row half (3 MIXED tiles = 24 channels), tile pair (32 tiles)
+  const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
+  const int tpi = p.th * p.tw;                 // tiles per image
+
+  // tile -> (batch, first output pixel).  iy walks the tile grid; y0 = 2d*(iy/d) + iy%d
+  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+    b = t / tpi;
+    const int rem = t - b * tpi;
+    const int iy = rem / p.tw, ix = rem - iy * p.tw;
+    const int qy = iy / p.d, qx = ix / p.d;
+    y0 = 2 * p.d * qy + (iy - qy * p.d);
+    x0 = 2 * p.d * qx + (ix - qx * p.d);
+  };
+
+  // ---- staging role: tile row srow, granule s (4 channels) of each 16-channel k-half
+  const int srow = tid >> 2, sg = tid & 3;
+  const int swz = (srow >> 1) & 7;
+  char* xw0 = Xb + srow * 128 + ((sg ^ swz) << 4);             // k-half 0: logical slot sg
+  char* xw1 = Xb + srow * 128 + (((4 + sg) ^ swz) << 4);       // k-half 1: logical slot 4 + sg
+  // Source offsets of the 4x4 input tile, kept in LDS (read once per position):
+  //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or -1 if outside / invalid tile
+  //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
+  int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
+  int* Xsrc = Ysrc + 4 * 512;
+  {
+    const int t = tile_base + srow;
+    int b, y0, x0;
+    tile_origin(t < p.total_tiles ? t : 0, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
+      Ysrc[i * 512 + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : -1;
+      Xsrc[i * 512 + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
+    }
+  }
+  const unsigned lds_w = lds_addr_of(Wb);
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+
+  unsigned o[2][4];     // [even / odd position of the pair]: byte offsets of the four source pixels
+  float g[2][4];        // their B^T factors (0 for a pixel outside the image: zero padding)
+  auto set_pos = [&](int set, int pos) {    // compile-time arguments after unrolling
+    const int xi = pos >> 2, nu = pos & 3;
+    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
+    const int ya = Ysrc[(xi == 0 ? 0 : 1) * 512 + tid], yb = Ysrc[(xi == 3 ? 3 : 2) * 512 + tid];
+    const int xa = Xsrc[(nu == 0 ? 0 : 1) * 512 + tid], xb = Xsrc[(nu == 3 ? 3 : 2) * 512 + tid];
+    const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = yb < 0 ? 0.f : ((xi == 0 || xi == 3) ? -1.f : 1.f);
+    const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = xb < 0 ? 0.f : ((nu == 0 || nu == 3) ? -1.f : 1.f);
+    // always load from a valid (clamped) address; the padding zero is applied through the factor
+    const unsigned ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
+    o[set][0] = ya_c + xa_c; o[set][1] = ya_c + xb_c; o[set][2] = yb_c + xa_c; o[set][3] = yb_c + xb_c;
+    g[set][0] = sxa * sya; g[set][1] = sxb * sya; g[set][2] = sxa * syb; g[set][3] = sxb * syb;
+  };
+  // k-half h of iteration it -> (position set, 16-channel group): see the chunk table in the header
+  auto half_set = [](int it, int h) { return (it % 3) * 2 + h >= 3 ? 1 : 0; };
+  auto half_grp = [](int it, int h) { return ((it % 3) * 2 + h) % 3; };
+  // one raw granule (pixel i of the 4 sources) of k-half h of iteration `it`: one vector-memory instruction
+  auto load_x1 = [&](int it, f32x4 (&r)[2][4], int h, int i) {
+    r[h][i] = *(const f32x4*)((const char*)p.src + half_grp(it, h) * 64 + (size_t)o[half_set(it, h)][i]);
+  };
+  auto write_x = [&](int it, int buf, const f32x4 (&r)[2][4]) {
+    const int s0 = half_set(it, 0), s1 = half_set(it, 1);
+    const f32x4 v0 = r[0][0] * g[s0][0] + r[0][1] * g[s0][1] + r[0][2] * g[s0][2] + r[0][3] * g[s0][3];
+    const f32x4 v1 = r[1][0] * g[s1][0] + r[1][1] * g[s1][1] + r[1][2] * g[s1][2] + r[1][3] * g[s1][3];
+    *(f32x4*)(xw0 + buf * XB) = v0;
+    *(f32x4*)(xw1 + buf * XB) = v1;
+  };
+  // W tile: 12 row blocks of 8 rows; wave w stages block w, and block 8 + w if w < 4
+  auto dma_w = [&](int it, int buf, int j) {
+    const int rbk = j * 8 + w;
+    if (rbk < 12) glds16_s(p.upk + (size_t)it * 96 * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WB + rbk * 1024);
+  };
+
+  f32x4 am[3][2];                      // position accumulators (row tile, tile group)
+  f32x4 oy[2][2][3][2];                // output accumulators (a, b, row tile, tile group)
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      am[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) oy[a][b][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  // fold the finished position: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1]; pos compile-time,
+  // so only the non-zero terms exist and they are plain adds / subtracts
+  auto fold = [&](int pos) {
+    const int xi = pos >> 2, nu = pos & 3;
+    const int ay[2] = {xi < 3 ? 1 : 0, xi == 0 ? 0 : (xi == 1 ? 1 : -1)};
+    const int ax[2] = {nu < 3 ? 1 : 0, nu == 0 ? 0 : (nu == 1 ? 1 : -1)};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int c = ay[a] * ax[b];
+            if (c > 0) oy[a][b][j][q] += am[j][q];
+            else if (c < 0) oy[a][b][j][q] -= am[j][q];
+          }
+        // pin the sums: hipcc would otherwise sink every fold to the end of the unrolled kernel
+        asm volatile("" : "+v"(oy[0][0][j][q]), "+v"(oy[0][1][j][q]), "+v"(oy[1][0][j][q]), "+v"(oy[1][1][j][q]));
+      }
+  };
+
+  // ---- pipeline (se_wino.hip), with every wait explicit and conservative: the granule loads are ordinary loads that
+  // hipcc tracks itself (an inline-asm load whose result register hipcc may copy before the data has landed is a
+  // latent race), and one s_waitcnt vmcnt(0) per iteration -- right before the granules of the PREVIOUS iteration
+  // are consumed -- also covers the W DMA of the previous iteration.  That DMA therefore targets a 4-slot ring, two
+  // barriers ahead of its first reader:
+  //   iteration it:  group 0 | vmcnt(0); X(it+2) <- granules loaded in it-1 | groups 1-4: granule loads of it+3,
+  //                  k-half 0 fragments of it+1 | groups 5-6: W DMA of it+3 | barrier
+  //   X(it+2): slot (it+2)%3, last read in it-1, published by this barrier, first read (fragments) in it+1
+  //   W(it+3): slot (it+3)%4, last read in it-1, complete after the vmcnt(0) of it+1, published by the barrier of
+  //            it+1, first read (fragments) in it+2
+  auto end_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: X slots 0, 1; W slots 0, 1, 2; granules of iteration 2 in flight
+  f32x4 r[2][4];
+  set_pos(0, 0);
+  set_pos(1, 1);
+#pragma unroll
+  for (int i0 = 0; i0 < 2; ++i0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { load_x1(i0, r, 0, i); load_x1(i0, r, 1, i); }
+    write_x(i0, i0, r);
+  }
+#pragma unroll
+  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); }
+  set_pos(0, 2);                       // even position of pair 1 (iteration 3 on)
+  dma_wait_all();
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { load_x1(2, r, 0, i); load_x1(2, r, 1, i); }
+
+  const char* Xw = Xb + tp * 32 * 128;                   // this wave's 32 tile rows
+  const char* Ww = Wb + (3 * chh) * 2048;                // this wave's 3 row tiles
+  f32x4 wa[3], xa[2];                  // k-half 0 fragments of the current iteration (read one iteration ahead)
+  xa[0] = *(const f32x4*)(Xw + off0);
+  xa[1] = *(const f32x4*)(Xw + 2048 + off0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + j * 2048 + off0);
+
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it % 3, pp = it / 3;
+    const int b0 = it % 3, b1 = (it + 1) % 3, b2 = (it + 2) % 3;      // X ring
+    const int w0 = it % 4, w1 = (it + 1) % 4, w3 = (it + 3) % 4;      // W ring
+    const bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
+    f32x4 wb[3], xb[2];
+    xb[0] = *(const f32x4*)(Xw + b0 * XB + off1);                  // k-half 1 fragments of this iteration
+    xb[1] = *(const f32x4*)(Xw + b0 * XB + 2048 + off1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wb[j] = *(const f32x4*)(Ww + w0 * WB + j * 2048 + off1);
+    __builtin_amdgcn_sched_barrier(0);
+    // one group = 6 MFMAs: k-step e of the 3 x 2 accumulator tiles; `first`: C = 0 (first k-step of a position)
+    auto group = [&](const f32x4 (&wf)[3], const f32x4 (&xf)[2], int e, bool first) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 cin = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : am[j][q];
+          am[j][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[q][e], cin, 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (c == 0 && it > 0) {              // chunk A: the odd position of the previous pair is complete
+      fold(2 * pp - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    group(wa, xa, 0, c == 0);
+    if (more2) {
+      dma_wait_all();                    // granules of it+2 and the W DMA of it+2, both issued an iteration ago
+      write_x(it + 2, b2, r);
+    }
+    // next use of a position set: even set after the last chunk-B write, odd set after the last chunk-C write
+    if (c == 2 && 2 * (pp + 2) < 16) set_pos(0, 2 * (pp + 2));
+    if (c == 0 && 2 * (pp + 1) + 1 < 16) set_pos(1, 2 * (pp + 1) + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // vector-memory instructions two per MFMA group (a burst from all 8 waves fills the CU's queue and stalls them)
+    group(wa, xa, 1, false);
+    if (more3) { load_x1(it + 3, r, 0, 0); load_x1(it + 3, r, 0, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    group(wa, xa, 2, false);
+    if (more3) { load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    group(wa, xa, 3, false);
+    if (more3) { load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
+    if (more1) {                                          // k-half 0 fragments of it+1 (published slots)
+      xa[0] = *(const f32x4*)(Xw + b1 * XB + off0);
+      xa[1] = *(const f32x4*)(Xw + b1 * XB + 2048 + off0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + w1 * WB + j * 2048 + off0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c == 1) {                        // chunk B: the even position ends with k-half 0, the odd one starts
+      fold(2 * pp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    group(wb, xb, 0, c == 1);
+    if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    group(wb, xb, 1, false);
+    if (more3) dma_w(it + 3, w3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    group(wb, xb, 2, false);
+    if (more3) dma_w(it + 3, w3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    group(wb, xb, 3, false);
+    end_barrier();
+  }
+  fold(15);
+
+  // ---- epilogue.  Lane (q = lane>>4, col = lane&15) holds rows 4q..4q+3 of every accumulator tile: features for
+  // q < 2, the matching gates for q >= 2; the gate lanes hand sigmoid to their feature lane (lane ^ 32).
+  const int q = lane >> 4;
+#pragma unroll
+  for (int tq = 0; tq < 2; ++tq) {
+    const int t = tile_base + tp * 32 + tq * 16 + (lane & 15);
+    int b = 0, y0 = 0, x0 = 0;
+    tile_origin(t < p.total_tiles ? t : 0, b, y0, x0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c0 = (3 * chh + j) * 8 + (q & 1) * 4;
+      const f32x4 bq = *(const f32x4*)(p.bias + (3 * chh + j) * 16 + q * 4);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          f32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = oy[a][bb][j][tq][e] + bq[e];
+            const float ex = fast_exp(q < 2 ? v : -v);
+            const float act = p.act == 0 ? (v > 0.f ? v : ex - 1.f) : fmaxf(v, 0.f);
+            const float tv = q < 2 ? act : fast_rcp(1.f + ex);
+            ov[e] = tv * __shfl_xor(tv, 32);
+          }
+          if (q < 2 && t < p.total_tiles)
+            *(f32x4*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 48 + c0) = ov;
+        }
+    }
+  }
+}
+
+hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
+  constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 8 * 512 * 4;     // X ring 48 KB + W ring 48 KB + source offsets
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wino48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = (p.total_tiles + 127) / 128;
+  ProfScope ps_(st, PL_WINO_N96);
+  hipLaunchKernelGGL(wino48_kernel, dim3(grid), dim3(512), LDS, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace se

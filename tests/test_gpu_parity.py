@@ -119,6 +119,25 @@ def test_op_winograd_path_vs_oracle(eng, case):
     assert _md(y, ref) < TOL_OP
 
 
+WINO48 = [(1, 16, 16, "elu"), (1, 64, 64, "elu"), (2, 16, 24, "relu"), (4, 32, 16, "elu"), (1, 10, 14, "elu"),
+          (1, 34, 30, "elu")]
+
+
+@pytest.mark.parametrize("case", WINO48, ids=["d%d-%dx%d-%s" % c for c in WINO48])
+def test_op_winograd48_path_vs_oracle(eng, case):
+    """48 -> 96 3x3 stride 1 (the 128x128 level of every encoder / decoder): Winograd kernel of se_wino48.hip --
+    three 32-k chunks per position pair, MIXED feature/gate rows; ragged tile counts and dilations included."""
+    from oracle import sketchedit_oracle as O
+    d, H, W, act = case
+    a = 1.5 / np.sqrt(48 * 9)
+    w = synth.uniform(17, "wino48.w%s" % (case,), (96, 48, 3, 3), -a, a)
+    b = synth.uniform(17, "wino48.b%s" % (case,), (96,), -0.3, 0.3)
+    x = synth.uniform(17, "wino48.x%s" % (case,), (3, 48, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act)
+    assert _md(y, ref) < TOL_OP
+
+
 def test_op_attention_vs_oracle(eng):
     from oracle import sketchedit_oracle as O
     x = synth.uniform(5, "att96.x", (2, 96, 12, 16), -1, 1)
