@@ -179,8 +179,10 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + j * 2048 + off0);
 
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int c = it % 3, pp = it / 3;
+  for (int pp = 0; pp < 8; ++pp)       // position pairs x chunks, fully unrolled: everything below is compile-time
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int it = pp * 3 + c;
     const int b0 = it % 3, b1 = (it + 1) % 3, b2 = (it + 2) % 3;      // X ring
     const int w0 = it % 4, w1 = (it + 1) % 4, w3 = (it + 3) % 4;      // W ring
     const bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
