@@ -16,6 +16,34 @@
 
 #include <cstdlib>
 
+// Developer aid (-DSE_WINO_TRACE, tools/wino_trace.py): s_memtime stamps of block 0 / waves 0 and 4, kept in LDS.
+#ifdef SE_WINO_TRACE
+__device__ unsigned long long g_wino48_trace[96 * 8];
+extern "C" int se_debug_wino48_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino48_trace), sizeof(unsigned long long) * 96 * 8);
+}
+#define W48_TRACE_LDS (3 * 128 * 128 + 4 * 96 * 128 + 8 * 512 * 4)
+#define W48_STAMP(k)                                                    \
+  do {                                                                  \
+    if (blockIdx.x == 0 && (w & 3) == 0) {                              \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+      if (lane == 0) ((unsigned long long*)(smem + W48_TRACE_LDS))[((w >> 2) * 48 + it) * 8 + (k)] = t_; \
+    }                                                                   \
+  } while (0)
+#define W48_STAMP_AT(slot, k) do { const int it = (slot); W48_STAMP(k); } while (0)
+#define W48_TRACE_DUMP()                                                \
+  do {                                                                  \
+    if (blockIdx.x == 0 && (w & 3) == 0)                                \
+      for (int i_ = lane; i_ < 48 * 8; i_ += 64)                        \
+        g_wino48_trace[(w >> 2) * 48 * 8 + i_] = ((unsigned long long*)(smem + W48_TRACE_LDS))[(w >> 2) * 48 * 8 + i_]; \
+  } while (0)
+#else
+#define W48_TRACE_LDS 0
+#define W48_STAMP(k)
+#define W48_STAMP_AT(slot, k)
+#define W48_TRACE_DUMP()
+#endif
+
 namespace se {
 
 __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
@@ -31,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   const int chh = w & 1, tp = w >> 1;          // row half (3 MIXED tiles = 24 channels), tile pair (32 tiles)
   const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
   const int tpi = p.th * p.tw;                 // tiles per image
+  W48_STAMP_AT(24, 0);
 
   // tile -> (batch, first output pixel).  iy walks the tile grid; y0 = 2d*(iy/d) + iy%d
   auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
@@ -115,6 +144,8 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
     }
   // fold the finished position: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1]; pos compile-time,
   // so only the non-zero terms exist and they are plain adds / subtracts
+  float neg1 = -1.f;
+  asm volatile("" : "+v"(neg1));      // opaque multiplier: keeps the subtraction a packed fma
   auto fold = [&](int pos) {
     const int xi = pos >> 2, nu = pos & 3;
     const int ay[2] = {xi < 3 ? 1 : 0, xi == 0 ? 0 : (xi == 1 ? 1 : -1)};
@@ -129,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
           for (int b = 0; b < 2; ++b) {
             const int c = ay[a] * ax[b];
             if (c > 0) oy[a][b][j][q] += am[j][q];
-            else if (c < 0) oy[a][b][j][q] -= am[j][q];
+            else if (c < 0) oy[a][b][j][q] = am[j][q] * neg1 + oy[a][b][j][q];     // v_pk_fma (a plain -= becomes 4 scalar v_sub)
           }
         // pin the sums: hipcc would otherwise sink every fold to the end of the unrolled kernel
         asm volatile("" : "+v"(oy[0][0][j][q]), "+v"(oy[0][1][j][q]), "+v"(oy[1][0][j][q]), "+v"(oy[1][1][j][q]));
@@ -141,8 +172,8 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   // latent race), and one s_waitcnt vmcnt(0) per iteration -- right before the granules of the PREVIOUS iteration
   // are consumed -- also covers the W DMA of the previous iteration.  That DMA therefore targets a 4-slot ring, two
   // barriers ahead of its first reader:
-  //   iteration it:  group 0 | vmcnt(0); X(it+2) <- granules loaded in it-1 | groups 1-4: granule loads of it+3,
-  //                  k-half 0 fragments of it+1 | groups 5-6: W DMA of it+3 | barrier
+  //   iteration it:  groups 0-3 | vmcnt(0); X(it+2) <- granules loaded in it-1 | groups 4-7: W DMA and granule loads
+  //                  of it+3, k-half 0 fragments of it+1 | barrier
   //   X(it+2): slot (it+2)%3, last read in it-1, published by this barrier, first read (fragments) in it+1
   //   W(it+3): slot (it+3)%4, last read in it-1, complete after the vmcnt(0) of it+1, published by the barrier of
   //            it+1, first read (fragments) in it+2
@@ -178,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + j * 2048 + off0);
 
+  W48_STAMP_AT(24, 1);
 #pragma unroll
   for (int pp = 0; pp < 8; ++pp)       // position pairs x chunks, fully unrolled: everything below is compile-time
 #pragma unroll
@@ -203,28 +235,33 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
         }
       __builtin_amdgcn_sched_barrier(0);
     };
+    W48_STAMP(0);
     if (c == 0 && it > 0) {              // chunk A: the odd position of the previous pair is complete
       fold(2 * pp - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     group(wa, xa, 0, c == 0);
+    group(wa, xa, 1, false);
+    group(wa, xa, 2, false);
+    group(wa, xa, 3, false);
+    W48_STAMP(1);
+    if (c == 1) {                        // chunk B: the even position ends with k-half 0, the odd one starts
+      fold(2 * pp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (more2) {
-      dma_wait_all();                    // granules of it+2 and the W DMA of it+2, both issued an iteration ago
+      dma_wait_all();                    // granules and W DMA issued in groups 4-7 of the previous iteration
       write_x(it + 2, b2, r);
     }
     // next use of a position set: even set after the last chunk-B write, odd set after the last chunk-C write
     if (c == 2 && 2 * (pp + 2) < 16) set_pos(0, 2 * (pp + 2));
     if (c == 0 && 2 * (pp + 1) + 1 < 16) set_pos(1, 2 * (pp + 1) + 1);
     __builtin_amdgcn_sched_barrier(0);
-    // vector-memory instructions two per MFMA group (a burst from all 8 waves fills the CU's queue and stalls them)
-    group(wa, xa, 1, false);
-    if (more3) { load_x1(it + 3, r, 0, 0); load_x1(it + 3, r, 0, 1); }
-    __builtin_amdgcn_sched_barrier(0);
-    group(wa, xa, 2, false);
-    if (more3) { load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
-    __builtin_amdgcn_sched_barrier(0);
-    group(wa, xa, 3, false);
-    if (more3) { load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
+    // vector-memory instructions spread over the MFMA groups (a burst from all 8 waves fills the CU's queue and
+    // stalls the waves, MFMAs included, in front of it)
+    W48_STAMP(2);
+    group(wb, xb, 0, c == 1);
+    if (more3) { dma_w(it + 3, w3, 0); load_x1(it + 3, r, 0, 0); load_x1(it + 3, r, 0, 1); }
     if (more1) {                                          // k-half 0 fragments of it+1 (published slots)
       xa[0] = *(const f32x4*)(Xw + b1 * XB + off0);
       xa[1] = *(const f32x4*)(Xw + b1 * XB + 2048 + off0);
@@ -232,26 +269,25 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
       for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + w1 * WB + j * 2048 + off0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (c == 1) {                        // chunk B: the even position ends with k-half 0, the odd one starts
-      fold(2 * pp);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    group(wb, xb, 0, c == 1);
-    if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
-    __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 1, false);
-    if (more3) dma_w(it + 3, w3, 0);
+    if (more3) { dma_w(it + 3, w3, 1); load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 2, false);
-    if (more3) dma_w(it + 3, w3, 1);
+    if (more3) { load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 3, false);
+    if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
+    W48_STAMP(3);
     end_barrier();
+    W48_STAMP(4);
   }
+  W48_STAMP_AT(24, 2);
   fold(15);
 
   // ---- epilogue.  Lane (q = lane>>4, col = lane&15) holds rows 4q..4q+3 of every accumulator tile: features for
-  // q < 2, the matching gates for q >= 2; the gate lanes hand sigmoid to their feature lane (lane ^ 32).
+  // q < 2 (lanes 0-31), the matching gates in lane + 32.  Two v_permlane32_swap per quad hand each lane two complete
+  // (feature, gate) pairs -- lanes 0-31 channels c0, c0+1, lanes 32-63 channels c0+2, c0+3 -- so every lane
+  // evaluates two outputs (a ds_bpermute exchange per value cost a quarter of the kernel's time).
   const int q = lane >> 4;
 #pragma unroll
   for (int tq = 0; tq < 2; ++tq) {
@@ -260,30 +296,32 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
     tile_origin(t < p.total_tiles ? t : 0, b, y0, x0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int c0 = (3 * chh + j) * 8 + (q & 1) * 4;
+      const int c0 = (3 * chh + j) * 8 + (q & 1) * 4 + (q >> 1) * 2;
       const f32x4 bq = *(const f32x4*)(p.bias + (3 * chh + j) * 16 + q * 4);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          f32x4 ov;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = oy[a][bb][j][tq][e] + bq[e];
-            const float ex = fast_exp(q < 2 ? v : -v);
-            const float act = p.act == 0 ? (v > 0.f ? v : ex - 1.f) : fmaxf(v, 0.f);
-            const float tv = q < 2 ? act : fast_rcp(1.f + ex);
-            ov[e] = tv * __shfl_xor(tv, 32);
-          }
-          if (q < 2 && t < p.total_tiles)
-            *(f32x4*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 48 + c0) = ov;
+          const f32x4 v = oy[a][bb][j][tq] + bq;
+          const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+          const float f0 = __uint_as_float(s02[0]), g0 = __uint_as_float(s02[1]);
+          const float f1 = __uint_as_float(s13[0]), g1 = __uint_as_float(s13[1]);
+          float2 ov;
+          ov.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(g0);
+          ov.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(g1);
+          if (t < p.total_tiles)
+            *(float2*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 48 + c0) = ov;
         }
     }
   }
+  W48_STAMP_AT(24, 3);
+  __syncthreads();
+  W48_TRACE_DUMP();
 }
 
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 8 * 512 * 4;     // X ring 48 KB + W ring 48 KB + source offsets
+  constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 8 * 512 * 4 + (W48_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 48 KB + W ring 48 KB + source offsets
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wino48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -23,11 +23,11 @@ def build():
     print("built", SO)
 
 
-def table(t, names, nstamp):
+def table(t, names, nstamp, nit=48):
     """t: [2 waves][48 iterations][8 stamps]; prints both waves' phase durations and their start offset."""
     t0 = t[0, 0, 0]
     print("it   " + "  ".join("%-9s" % n for n in names) + " total | wave 4: start " + "  ".join("%-9s" % n for n in names) + " total")
-    for it in range(48):
+    for it in range(nit):
         row = "%2d   " % it
         for wv in range(2):
             d = [t[wv, it, k + 1] - t[wv, it, k] for k in range(nstamp - 1)]
@@ -35,7 +35,8 @@ def table(t, names, nstamp):
                 row += " |         %6d " % (t[1, it, 0] - t0)
             row += "  ".join("%-9d" % v for v in d) + " %5d" % (t[wv, it, nstamp - 1] - t[wv, it, 0])
         print(row)
-    print("iterations 0..46: %d cycles, mean per iteration %.0f" % (t[0, 46, nstamp - 1] - t[0, 0, 0], (t[0, 46, nstamp - 1] - t[0, 0, 0]) / 47.0))
+    last = nit - 2
+    print("iterations 0..%d: %d cycles, mean per iteration %.0f" % (last, t[0, last, nstamp - 1] - t[0, 0, 0], (t[0, last, nstamp - 1] - t[0, 0, 0]) / (last + 1.0)))
 
 
 def run():
@@ -61,5 +62,31 @@ def run():
     table(t, ["6mfma", "24mfma", "xw+18mfma", "barrier"], 5)
 
 
+def run48():
+    os.environ["SKETCHEDIT_HIP_LIB"] = SO
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    from sketchedit_amd import synth
+    from sketchedit_amd._lib import Engine
+    a = 1.5 / np.sqrt(48 * 9)
+    w = synth.uniform(1, "t.w", (96, 48, 3, 3), -a, a)
+    b = synth.uniform(1, "t.b", (96,), -0.1, 0.1)
+    x = torch.from_numpy(synth.uniform(1, "t.x", (32, 48, 128, 128), -1, 1)).cuda()
+    lib = ctypes.CDLL(SO)
+    buf = (ctypes.c_ulonglong * (96 * 8))()
+    eng = Engine(0)
+    for _ in range(3):
+        eng.gated_conv2d(x, w, b)
+    torch.cuda.synchronize()
+    assert lib.se_debug_wino48_trace(buf) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 48, 8).astype(np.int64)
+    print("== wino48_kernel (se_wino48.hip)")
+    table(t, ["24mfma", "fold/xwrite", "24mfma+ld", "barrier"], 5, nit=24)
+    for wv in range(2):
+        e = t[wv, 24]
+        print("wave %d: prologue %d  loop %d  epilogue %d cycles" % (wv * 4, e[1] - e[0], e[2] - e[1], e[3] - e[2]))
+
+
 if __name__ == "__main__":
-    {"build": build, "run": run}[sys.argv[1]]()
+    {"build": build, "run": run, "run48": run48}[sys.argv[1]]()
