@@ -6,7 +6,7 @@
 Corrections (MI355X_MICROARCH.md): FETCH_SIZE is doubled (gfx950 counts 128-B read requests at 64 B);
 FETCH/WRITE_SIZE are in KiB; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is summed
 over the 1024 SIMDs.  --json writes {kernel label: HBM bytes per launch (read+write)} for bench.py's
-roofline.traffic.
+roofline.traffic (launch-weighted mean over the kernels that share a label).
 """
 import collections
 import csv
@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-LABELS = {"wino_kernel": "wino_n192", "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96",
+LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96",
           "gconv_kernel<3": "gconv_n48", "gconv_kernel<2": "gconv_n24"}
 
 
@@ -39,7 +39,8 @@ def main(argv):
     out_json = None
     if argv and argv[0] == "--json":
         out_json, argv = argv[1], argv[2:]
-    traffic = collections.defaultdict(float)
+    traffic = collections.defaultdict(float)      # label -> bytes summed over launches (read + write passes)
+    launches = collections.defaultdict(lambda: collections.defaultdict(int))   # label -> pass dir -> launches
     for d in argv:
         agg = load(d)
         print("== %s (mean per dispatch)" % d)
@@ -63,16 +64,19 @@ def main(argv):
                 b = 2 * c["FETCH_SIZE"] * 1024
                 line += "  HBM_read=%.1f MB (2x FETCH_SIZE)" % (b / 1e6)
                 if lab:
-                    traffic[lab] += b
+                    traffic[lab] += b * n
+                    launches[lab][d] += n
             if "WRITE_SIZE" in c:
                 b = c["WRITE_SIZE"] * 1024
                 line += "  HBM_write=%.1f MB" % (b / 1e6)
                 if lab:
-                    traffic[lab] += b
+                    traffic[lab] += b * n
+                    launches[lab][d] += n
             print(line)
     if out_json:
         json.dump({"unit": "bytes per launch (HBM read + write, rocprofv3 PMC, FETCH_SIZE x2)",
-                   "kernels": {k: round(v) for k, v in traffic.items()}}, open(out_json, "w"), indent=1)
+                   "kernels": {k: round(v / max(max(launches[k].values()), 1)) for k, v in traffic.items()}},
+                  open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
