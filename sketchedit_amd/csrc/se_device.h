@@ -40,17 +40,6 @@ DEVFN void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
       : "v"(voff), "s"(sbase), "s"(lds_addr)
       : "memory");
 }
-// 16-byte global load, scalar base + 32-bit lane offset, issued outside hipcc's vmcnt bookkeeping: the caller orders
-// it against its DMA with explicit s_waitcnt vmcnt(n) (wait_loaded) -- hipcc itself would wait with vmcnt(0), i.e.
-// also for every younger DMA it does not know about.
-DEVFN void gload16(f32x4& dst, unsigned voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-template <int N>
-DEVFN void wait_loaded(f32x4 (&r)[4]) {     // at most N younger vector-memory operations may still be in flight
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
-}
-
 // LDS-DMA through a buffer resource: lanes whose byte offset is outside [0, num_records) deliver ZEROS to LDS
 // (hardware range check), which is how zero padding is staged without a zero page or a pointer select.
 typedef int se_i32x4 __attribute__((ext_vector_type(4)));

@@ -11,8 +11,8 @@
 //
 // One workgroup = 8 waves (two per SIMD) = 64 tiles x all 192 packed channels; wave w owns 16 tiles (MFMA columns)
 // and one half of the channels (3 feature tiles + their 3 gate tiles, so the gate is a register epilogue).
-// Loop over it = (position, 32-k chunk), 48 (96 with two sources) iterations, fully unrolled, three-slot LDS ring,
-// one barrier per iteration:
+// Loop over it = (position, 32-k chunk), 48 (96 with two sources) iterations, fully unrolled, LDS rings of 3 X and 4 W
+// tiles, one barrier per iteration:
 //   * X tile [64 tiles][32 k]: each lane builds ONE granule = (B^T x B) at this position from 4 raw input granules
 //     (global loads issued an iteration earlier) and writes it to LDS -- the input transform is fused, no
 //     transformed tensor ever exists in HBM;
@@ -28,11 +28,13 @@
 //      C = 0 instead of zeroed registers, the fold generates only its 12 (of 16) non-zero terms, and there is one
 //      accumulator set -- a second one to "hide" the fold buys nothing and costs 24 registers.
 //   2. A wave that issues its 7 vector-memory instructions back to back (all 8 waves do so at the same point) stalls
-//      ~1000 cycles in front of the full vector-memory queue and cannot issue MFMAs meanwhile: they are issued one
-//      per MFMA group.
+//      ~1000 cycles in front of the full vector-memory queue and cannot issue MFMAs meanwhile: they are spread
+//      over the MFMA groups of the second half of the iteration.
 //   3. The k-half 0 fragments of the next iteration are read before the barrier (its slot was published one barrier
 //      earlier), so the MFMA stream continues straight across the barrier.
-// Per-launch time 200 -> 168 us (B=32, 64x64; 115 TF/s executed = 73 % of the fp32 MFMA peak, 258 TF/s in direct-
+//   4. Granules and W DMA are waited for (one vmcnt(0)) half an iteration after they were issued; the W tile goes
+//      to a 4-slot ring two barriers ahead of its reader so that this one conservative wait is enough.
+// Per-launch time 200 -> 166 us (B=32, 64x64; 115 TF/s executed = 73 % of the fp32 MFMA peak, 258 TF/s in direct-
 // convolution terms).  Tried and NOT faster: a ping-pong split (waves 0-3 / 4-7 one phase apart, two barriers per
 // iteration: 237 us), two 4-wave workgroups per CU, 16-wave workgroups with an LDS gate exchange, raw granules in
 // registers, an "LDS patch" form without global loads in the loop, two positions per barrier.
@@ -48,7 +50,7 @@ extern "C" int se_debug_wino_trace(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_trace), sizeof(unsigned long long) * 96 * 8);
 }
 // stamps go to LDS (a global store per stamp would sit in vmcnt and distort the waits being measured)
-#define WINO_TRACE_LDS (3 * 64 * 128 + 3 * 192 * 128 + 8 * 512 * 4)
+#define WINO_TRACE_LDS (3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4)
 #define WINO_STAMP(k)                                                   \
   do {                                                                  \
     if (blockIdx.x == 0 && (w & 3) == 0) {                              \
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   // Source offsets of the 4x4 input tile, kept in LDS (read once per position; registers are the scarce resource):
   //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or -1 if outside / invalid tile
   //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
-  int* Ysrc = (int*)(smem + 3 * XB + 3 * WB);
+  int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
   int* Xsrc = Ysrc + 4 * 512;
   const unsigned lane_coff = (unsigned)s_log * 16u;
   int bimg;             // batch index of this lane's tile (address of the per-image vector source)
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
     const bool second = NCHK == 6 && chunk >= 3;
     const char* base = (const char*)(second ? p.src1 : p.src) + (second ? chunk - 3 : chunk) * 128;
     // spatially constant second source (pooled style vector): one value per image, still zero padded
-    if (second && p.src1_vec) gload16(r[i], vec_off, base);
-    else gload16(r[i], o[i], base);
+    if (second && p.src1_vec) r[i] = *(const f32x4*)(base + (size_t)vec_off);
+    else r[i] = *(const f32x4*)(base + (size_t)o[i]);
   };
   auto load_x = [&](int chunk, f32x4 (&r)[4]) {
 #pragma unroll
@@ -197,37 +199,39 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
                       "+v"(og[0][0][j]), "+v"(og[0][1][j]), "+v"(og[1][0][j]), "+v"(og[1][1][j]));
   };
 
-  // ---- pipeline.  Three-slot ring of LDS tiles; one workgroup barrier per iteration.  During iteration `it`:
-  //   * the W tile of it+2 is DMA'd into slot (it+2)%3 (free since the barrier that ended it-1) and the X tile of
-  //     it+2 is transformed into the same slot from the granules loaded an iteration ago;
-  //   * the raw granules of it+3 are fetched into registers;
-  //   * the k-half 0 fragments of it+1 are read before the barrier (slot published by the previous barrier), so the
-  //     MFMA stream continues straight across it.
-  // The DMA of this iteration is complete (vmcnt leaves only the 4 younger granule loads outstanding) before the
-  // barrier that publishes the slot.  No scratch (spill) access may sit between the DMA and that wait.
-  // (The two-source instantiation spills a few LDS base addresses inside the loop; scratch traffic is vector memory
-  // too and would break the exact counts, so it waits with vmcnt(0) instead.)
-  constexpr bool EXACT = NCHK == 3;
-  auto end_barrier = [&](bool loads_in_flight) {
+  // ---- pipeline.  One workgroup barrier per iteration; X tiles in a 3-slot, W tiles in a 4-slot LDS ring.
+  //   iteration it:  groups 0-3 | vmcnt(0); X(it+2) <- granules loaded in it-1 | groups 4-7: W DMA and granule loads
+  //                  of it+3, k-half 0 fragments of it+1 | barrier
+  //   X(it+2): slot (it+2)%3, last read in it-1, published by this barrier, first read (fragments) in it+1
+  //   W(it+3): slot (it+3)%4, last read in it-1, complete after the vmcnt(0) of it+1, published by the barrier of
+  //            it+1, first read (fragments) in it+2
+  // Every wait is explicit and conservative.  The granule loads are ordinary loads that hipcc tracks itself (an
+  // inline-asm load whose result register hipcc may copy before the data has landed is a latent race: it showed up
+  // as run-to-run differences at batch 32 in se_wino48.hip), and the single s_waitcnt vmcnt(0) of an iteration sits
+  // half an iteration after the youngest vector-memory instruction was issued.  The fragments of it+1 are read
+  // before the barrier (their slots were published a barrier ago), so the MFMA stream runs straight across it.
+  auto end_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
-    if (EXACT && loads_in_flight) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  // ---- prologue: X slots 0, 1; W slots 0, 1, 2; granules of iteration 2 in flight
   f32x4 r[4];
   set_pos(0, 0);
 #pragma unroll
-  for (int i0 = 0; i0 < 2; ++i0) {     // ring slots 0 and 1 (chunks 0, 1 of position 0)
+  for (int i0 = 0; i0 < 2; ++i0) {     // chunks 0, 1 of position 0
     load_x(i0, r);
+    write_x(i0, r);
+  }
+#pragma unroll
+  for (int i0 = 0; i0 < 3; ++i0) {
     dma_w(i0, i0, 0);
     dma_w(i0, i0, 1);
     dma_w(i0, i0, 2);
-    wait_loaded<0>(r);
-    write_x(i0, r);
   }
-  load_x(2, r);                        // granules of iteration 2 (chunk 2 of position 0)
   dma_wait_all();
   __syncthreads();
+  load_x(2, r);                        // granules of iteration 2 (chunk 2 of position 0)
   f32x4 wf[3], wg[3], xh;              // k-half 0 fragments of the current iteration (read one iteration ahead)
   xh = *(const f32x4*)(Xb + tg * 2048 + off0);
 #pragma unroll
@@ -241,10 +245,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
     for (int k = 0; k < 4 * NCHK; ++k) {
       const int it = xi * 4 * NCHK + k;
       const int nu = k / NCHK, chunk = k % NCHK;
-      const int b0 = k % 3, b1 = (k + 1) % 3, b2 = (k + 2) % 3;     // == (it + i) % 3: 4*NCHK is a multiple of 3
+      const int b0 = k % 3, b1 = (k + 1) % 3, b2 = (k + 2) % 3;     // X ring; == (it + i) % 3: 4*NCHK is a multiple of 3
+      const int w0 = k % 4, w1 = (k + 1) % 4, w3 = (k + 3) % 4;     // W ring; == (it + i) % 4: 4*NCHK is a multiple of 4
       const char* Xt = Xb + b0 * XB + tg * 2048;
-      const char* Wf = Wb + b0 * WB + (3 * chh) * 2048;
-      const char* Wg = Wb + b0 * WB + (6 + 3 * chh) * 2048;
+      const char* Wf = Wb + w0 * WB + (3 * chh) * 2048;
+      const char* Wg = Wb + w0 * WB + (6 + 3 * chh) * 2048;
       const bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
       WINO_STAMP(0);
       f32x4 wf1[3], wg1[3], xh1;
@@ -273,53 +278,45 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
         fold(af, ag, pxi, pnu, 2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // The 7 vector-memory instructions of an iteration (3 W DMA pieces, 4 granule loads) are issued one per MFMA
-      // group: issued back to back by all 8 waves they fill the CU's vector-memory queue, and a wave stuck in
-      // front of a full queue cannot issue its MFMAs either.  The granules are consumed a full iteration after
-      // their loads were issued (vmcnt(3): everything but this iteration's three DMA pieces has landed).
       group(wf, wg, xh, 0, chunk == 0);
-      if (more2) dma_w(it + 2, b2, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      WINO_STAMP(1);
       group(wf, wg, xh, 1, false);
-      if (more2) dma_w(it + 2, b2, 1);
-      __builtin_amdgcn_sched_barrier(0);
       group(wf, wg, xh, 2, false);
-      if (more2) dma_w(it + 2, b2, 2);
-      __builtin_amdgcn_sched_barrier(0);
       group(wf, wg, xh, 3, false);
-      if (more1) {                                          // k-half 0 fragments of it+1 (published slot)
-        const char* Xn = Xb + b1 * XB + tg * 2048;
-        xh = *(const f32x4*)(Xn + off0);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          wf[j] = *(const f32x4*)(Wb + b1 * WB + (3 * chh + j) * 2048 + off0);
-          wg[j] = *(const f32x4*)(Wb + b1 * WB + (6 + 3 * chh + j) * 2048 + off0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      group(wf1, wg1, xh1, 0, false);
-      WINO_STAMP(2);
+      WINO_STAMP(1);
       if (more2) {
-        wait_loaded<EXACT ? 3 : 0>(r);     // granules of it+2, issued an iteration ago
+        dma_wait_all();                    // granules and W DMA issued in groups 4-7 of the previous iteration
         write_x(b2, r);
       }
       if ((k + 3) % NCHK == 0 && more3)    // position of the granules fetched next
         set_pos(xi + ((k + 3) / NCHK) / 4, ((k + 3) / NCHK) & 3);
       __builtin_amdgcn_sched_barrier(0);
-      if (more3) load_x1((k + 3) % NCHK, r, 0);
+      WINO_STAMP(2);
+      // The 7 vector-memory instructions of an iteration (3 W DMA pieces, 4 granule loads) are spread over the MFMA
+      // groups: issued back to back by all 8 waves they fill the CU's vector-memory queue, and a wave stuck in
+      // front of a full queue cannot issue its MFMAs either.
+      group(wf1, wg1, xh1, 0, false);
+      if (more3) { dma_w(it + 3, w3, 0); load_x1((k + 3) % NCHK, r, 0); }
+      if (more1) {                                          // k-half 0 fragments of it+1 (published slots)
+        const char* Xn = Xb + b1 * XB + tg * 2048;
+        xh = *(const f32x4*)(Xn + off0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          wf[j] = *(const f32x4*)(Wb + w1 * WB + (3 * chh + j) * 2048 + off0);
+          wg[j] = *(const f32x4*)(Wb + w1 * WB + (6 + 3 * chh + j) * 2048 + off0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       group(wf1, wg1, xh1, 1, false);
-      if (more3) load_x1((k + 3) % NCHK, r, 1);
+      if (more3) { dma_w(it + 3, w3, 1); load_x1((k + 3) % NCHK, r, 1); }
       __builtin_amdgcn_sched_barrier(0);
       group(wf1, wg1, xh1, 2, false);
-      if (more3) load_x1((k + 3) % NCHK, r, 2);
+      if (more3) { dma_w(it + 3, w3, 2); load_x1((k + 3) % NCHK, r, 2); }
       __builtin_amdgcn_sched_barrier(0);
       group(wf1, wg1, xh1, 3, false);
       if (more3) load_x1((k + 3) % NCHK, r, 3);
       __builtin_amdgcn_sched_barrier(0);
       WINO_STAMP(3);
-      end_barrier(more3);
+      end_barrier();
       WINO_STAMP(4);
     }
   }
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 
 template <int NCHK>
 static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 64 * 128 + 3 * 192 * 128 + 8 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // three-slot ring of X and W tiles (96 KB) + source offsets
+  constexpr int LDS = 3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 24 KB + W ring 96 KB + source offsets
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<NCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
