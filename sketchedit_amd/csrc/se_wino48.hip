@@ -72,7 +72,9 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   };
 
   // ---- staging role: tile row srow, granule s (4 channels) of each 16-channel k-half
-  const int srow = tid >> 2, sg = tid & 3;
+  // 8 consecutive lanes = rows R and R+8 (swizzles 4 apart): their 4+4 granules of one k-half fill one 128-byte
+  // bank row, so the LDS writes are conflict-free
+  const int sg = tid & 3, srow = (tid >> 6) * 16 + ((tid >> 2) & 1) * 8 + ((tid >> 3) & 7);
   const int swz = (srow >> 1) & 7;
   char* xw0 = Xb + srow * 128 + ((sg ^ swz) << 4);             // k-half 0: logical slot sg
   char* xw1 = Xb + srow * 128 + (((4 + sg) ^ swz) << 4);       // k-half 1: logical slot 4 + sg
