@@ -212,26 +212,26 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       }
     }
   } else {
-    // tile rows 0-7: features 8nt..8nt+7 (lanes q=0,1); rows 8-15: the matching gates (lanes q=2,3)
+    // tile rows 0-7: features 8nt..8nt+7 (lanes q=0,1 = lanes 0-31); rows 8-15: the matching gates (lane + 32).
+    // Two v_permlane32_swap per quad give every lane two complete (feature, gate) pairs -- lanes 0-31 channels
+    // c0, c0+1, lanes 32-63 channels c0+2, c0+3 -- so each lane evaluates two outputs; the former per-value
+    // ds_bpermute exchange cost these narrow layers about as much as a third of their MFMAs.
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int c0 = nt * 8 + (q & 1) * 4;
+      const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
       const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // feature lanes (q<2) and gate lanes (q>=2) share ONE exp: e = exp(v) for features (ELU's negative
-          // side), e = exp(-v) for gates (sigmoid); the gate lanes then ship sigmoid to their feature lane.
-          const float v = acc[nt][pt][r] + bq[r];
-          const float e = fast_exp(q < 2 ? v : -v);
-          const float a = p.act == 0 ? (v > 0.f ? v : e - 1.f) : fmaxf(v, 0.f);
-          const float t = q < 2 ? a : fast_rcp(1.f + e);
-          o[r] = t * __shfl_xor(t, 32);
-        }
-        if (q < 2 && c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + out_off(pidx) + c0) = o;
+        const f32x4 v = acc[nt][pt] + bq;
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+        const float f0 = __uint_as_float(s02[0]), g0 = __uint_as_float(s02[1]);
+        const float f1 = __uint_as_float(s13[0]), g1 = __uint_as_float(s13[1]);
+        float2 o;
+        o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(g0);
+        o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(g1);
+        if (c0 < p.G && pidx < p.total_pix) *(float2*)(p.dst + out_off(pidx) + c0) = o;
       }
     }
   }
