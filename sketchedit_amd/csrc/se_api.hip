@@ -409,6 +409,10 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) >= 2147483648.0 || (double)B * Ho * Wo * L.G >= 2147483648.0)
     return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
   p.ushift = 0;
+  p.rep = 0;
+  for (int j = 0; j < p.magicKH; ++j) p.rep |= 1u << (j * KW);
+  udiv_magic_host((unsigned)(p.Ho * p.Wo), &p.div_hw_m, &p.div_hw_l);
+  udiv_magic_host((unsigned)p.Wo, &p.div_w_m, &p.div_w_l);
   p.Hlim = Hin; p.Wlim = Win;
   p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * p.Ho * p.Wo;
   p.xcd = xcd_remap_enabled();

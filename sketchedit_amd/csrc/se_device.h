@@ -78,6 +78,14 @@ DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEVFN float elu_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
 DEVFN float sigmoid_fast(float x) { return fast_rcp(1.f + fast_exp(-x)); }
 
+// ---- division by a launch-invariant divisor (Granlund-Montgomery, round-up form): exact for every 32-bit x.
+// Host (se_kernels.h udiv_magic_host): l = ceil(log2 d), m = floor(2^32 * (2^l - d) / d) + 1.  Device: 2 shifts, 1 mul_hi, 2 adds instead of the
+// ~30-instruction software division hipcc emits for a runtime divisor.
+DEVFN unsigned udiv_magic(unsigned x, unsigned m, int l) {
+  const unsigned t = __umulhi(m, x);
+  return (t + ((x - t) >> (l < 1 ? l : 1))) >> (l > 1 ? l - 1 : 0);
+}
+
 // ---- XCD-aware tile order ---------------------------------------------------------------------------
 // The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md); each XCD has its own L2.
 // Remap so that every XCD walks one CONTIGUOUS eighth of the tile list: vertically adjacent tiles (which

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     const int pidx = tile_base + r;
     int2 e = make_int2(0, 0x40000000);
     if (pidx < p.total_pix) {
-      const int b = pidx / HoWo, rem = pidx - b * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int b = (int)udiv_magic((unsigned)pidx, p.div_hw_m, p.div_hw_l), rem = pidx - b * HoWo;
+      const int oy = (int)udiv_magic((unsigned)rem, p.div_w_m, p.div_w_l), ox = rem - oy * p.Wo;
       e = make_int2(b, ((oy * p.stride) << 16) | (ox * p.stride));
     }
     rowtab[r] = e;
@@ -69,10 +69,21 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       const int y0 = e.y >> 16, x0 = e.y & 0xffff;       // invalid rows: y0 = 16384, every tap fails the row test
       pixoff[i] = (unsigned)((e.x * p.Hin + y0) * p.Win + x0) * (unsigned)(p.C0 * 4);
       const int KH = p.magicKH;
-      unsigned colbits = 0, mask = 0;
-      for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(x0 + kx * p.dil - padx) < (unsigned)p.Wlim ? 1u : 0u) << kx;
-      for (int ky = 0; ky < KH; ++ky)
-        if ((unsigned)(y0 + ky * p.dil - pady) < (unsigned)p.Hlim) mask |= colbits << (ky * p.KW);
+      unsigned mask = 0;
+      if (p.dil == 1) {
+        // closed form: taps kx in [padx - x0, Wlim - 1 + padx - x0] (clipped to the kernel) are inside, same for ky;
+        // the column mask is replicated to every kernel row by one multiply and cut to the valid rows
+        const int clo = max(padx - x0, 0), chi = min(p.Wlim - 1 + padx - x0, p.KW - 1);
+        const int rlo = max(pady - y0, 0), rhi = min(p.Hlim - 1 + pady - y0, KH - 1);
+        const unsigned colbits = chi >= clo ? (2u << chi) - (1u << clo) : 0u;
+        const unsigned rowsel = rhi >= rlo ? (2u << (rhi * p.KW + p.KW - 1)) - (1u << (rlo * p.KW)) : 0u;
+        mask = __umul24(colbits, p.rep) & rowsel;
+      } else {
+        unsigned colbits = 0;
+        for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(x0 + kx * p.dil - padx) < (unsigned)p.Wlim ? 1u : 0u) << kx;
+        for (int ky = 0; ky < KH; ++ky)
+          if ((unsigned)(y0 + ky * p.dil - pady) < (unsigned)p.Hlim) mask |= colbits << (ky * p.KW);
+      }
       inv[i] = ~mask;                                     // bits >= T stay set: K padding reads zeros
     }
   }
@@ -186,8 +197,8 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   const int q = lane >> 4;
   auto out_off = [&](int pidx) -> size_t {
     if (!p.up2) return (size_t)pidx * p.G;
-    const int b = pidx / HoWo, rem = pidx - b * HoWo;
-    const int yy = rem / p.Wo, xx = rem - yy * p.Wo;
+    const int b = (int)udiv_magic((unsigned)pidx, p.div_hw_m, p.div_hw_l), rem = pidx - b * HoWo;
+    const int yy = (int)udiv_magic((unsigned)rem, p.div_w_m, p.div_w_l), xx = rem - yy * p.Wo;
     return ((size_t)(b * p.OH + 2 * yy + py) * p.OW + 2 * xx + px) * p.G;
   };
   if (!MIXED) {

@@ -45,6 +45,9 @@ struct GConvParams {
   int T, KW;           // taps, taps per kernel row
   int magicCG, magicKW; // x/CG == (x*magicCG)>>16, t/KW == (t*magicKW)>>8 on the ranges used (host-verified)
   int magicKH;          // kernel rows T / KW
+  unsigned rep;         // sum over kernel rows j of 1 << (j*KW): replicates a column-validity mask to every row
+  unsigned div_hw_m, div_w_m;   // exact x / (Ho*Wo) and x / Wo for x < 2^32 (se_device.h udiv_magic), with
+  int div_hw_l, div_w_l;        // their shift counts
   int stride, dil, pad;
   int ushift;          // 1: source is read through a nearest x2 upsample (coords >> 1)
   int up2;             // 1: sub-pixel form of nearest-x2 + 3x3: blockIdx.y = output parity class (py,px), a 2x2 conv
@@ -58,6 +61,14 @@ struct GConvParams {
   int total_pix;       // B*Ho*Wo
   int xcd;             // 1: XCD-aware tile order (se_device.h xcd_tile)
 };
+
+// magic numbers of se_device.h udiv_magic for divisor d >= 1
+static inline void udiv_magic_host(unsigned d, unsigned* m, int* l) {
+  int ll = 0;
+  while ((1ull << ll) < d) ++ll;
+  *l = ll;
+  *m = (unsigned)(((1ull << 32) * ((1ull << ll) - d)) / d + 1);
+}
 
 enum GConvCfg { GC_N192 = 0, GC_N96 = 1, GC_N48 = 2, GC_N24 = 3 };
 // rows (packed output channels) of each config
