@@ -375,6 +375,9 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
+    udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
+    udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
+    udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
     set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name);
     HIPCHK(c, launch_wino(wp, c->st));
@@ -389,6 +392,9 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
+    udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
+    udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
+    udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
     set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 48, d.name);
     HIPCHK(c, launch_wino48(wp, c->st));
     return 0;

@@ -93,6 +93,8 @@ struct WinoParams {
   int total_tiles;     // B*th*tw
   int act;             // 0 ELU, 1 ReLU
   int xcd;             // 1: XCD-aware tile order
+  unsigned div_tpi_m, div_tw_m, div_d_m;   // udiv_magic numbers for th*tw, tw and d
+  int div_tpi_l, div_tw_l, div_d_l;
 };
 hipError_t launch_wino(const WinoParams& p, hipStream_t st);
 // 48 -> 96 form (se_wino48.hip): src / dst NHWC 48 channels, upk [24 iterations][96 MIXED rows][32], bias [96] MIXED order

@@ -63,10 +63,10 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
 
   // tile -> (batch, first output pixel).  iy walks the tile grid; y0 = 2d*(iy/d) + iy%d
   auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
-    b = t / tpi;
+    b = (int)udiv_magic((unsigned)t, p.div_tpi_m, p.div_tpi_l);
     const int rem = t - b * tpi;
-    const int iy = rem / p.tw, ix = rem - iy * p.tw;
-    const int qy = iy / p.d, qx = ix / p.d;
+    const int iy = (int)udiv_magic((unsigned)rem, p.div_tw_m, p.div_tw_l), ix = rem - iy * p.tw;
+    const int qy = (int)udiv_magic((unsigned)iy, p.div_d_m, p.div_d_l), qx = (int)udiv_magic((unsigned)ix, p.div_d_m, p.div_d_l);
     y0 = 2 * p.d * qy + (iy - qy * p.d);
     x0 = 2 * p.d * qx + (ix - qx * p.d);
   };
