@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void att_pv_kernel(const AttParams p) {
   for (int k = 0; k < 3; ++k) {
     const int gidx = (k * 4 + w) * 64 + lane;
     vjr[k] = gidx / 24;
-    vcg[k] = gidx - vjr[k] * 24;
+    // bank swizzle: key rows j and j+4 (read by lane groups q and q+1 of one ds_read_b32) would hit the same 16 banks
+    // (row stride 96 floats = 3 bank rows); rows with bit 2 set keep their granules swapped in blocks of 4
+    vcg[k] = (gidx - vjr[k] * 24) ^ (((vjr[k] >> 2) & 1) << 2);
   }
 
   auto stage = [&](int ch, int buf) {
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void att_pv_kernel(const AttParams p) {
     if (ch + 1 < nch) stage(ch + 1, buf ^ 1);
     const char* Xt = Xb + buf * XBYTES + w * PT * 2048;
     const float* Vt = (const float*)(Vb + buf * VBYTES);
+    const int vsw = ((lane >> 4) & 1) << 4;          // (j >> 2) & 1 == (lane >> 4) & 1: see the V staging swizzle
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int off = half ? off1 : off0;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void att_pv_kernel(const AttParams p) {
         const int j = half * 16 + (lane >> 4) * 4 + r;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const float a = Vt[j * 96 + nt * 16 + (lane & 15)];
+          const float a = Vt[j * 96 + ((nt * 16 + (lane & 15)) ^ vsw)];
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt)
             acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[pt][r], acc[nt][pt], 0, 0, 0);
