@@ -161,49 +161,70 @@ __global__ __launch_bounds__(256) void att_pv_kernel(const AttParams p) {
   const int b = blockIdx.z, cls = blockIdx.y, py = cls >> 1, px = cls & 1;
   const int ch_ = p.h >> 1, cw_ = p.w >> 1;      // class image size
   const int t0 = blockIdx.x * PIX;
-  int ryx[NX];
+  // Staging through buffer resources of THIS image's score matrix and value tensor (32-bit offsets, hardware zero
+  // fill for out-of-range lanes; se_gconv.hip fast path): per P row one byte offset and a 4-bit validity mask over
+  // the (a, bb) patch combos, per V granule the key's pixel offset -- 3 VALU per staged granule in the loop.
+  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
+  const se_i32x4 rs_S = make_rsrc(p.S + (size_t)b * p.L * p.Lp, (unsigned)p.L * p.Lp * 4u);
+  const se_i32x4 rs_x = make_rsrc(p.x + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
+  unsigned xoff[NX], xinv[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int r = t0 + (i * 4 + w) * 8 + (lane >> 3);
-    ryx[i] = r < ch_ * cw_ ? (((r / cw_) << 16) | (r % cw_)) : 0x40000000;
+    const bool rowok = r < ch_ * cw_;
+    const int ry = rowok ? r / cw_ : 0, rx = rowok ? r - (r / cw_) * cw_ : 0;
+    xoff[i] = (unsigned)((ry * p.ws + rx) * p.Lp + s_log * 4) * 4u;
+    unsigned m = 0;
+#pragma unroll
+    for (int combo = 0; combo < 4; ++combo) {
+      const int iy = ry - (combo >> 1), ix = rx - (combo & 1);
+      if (rowok && (unsigned)iy < (unsigned)p.hs && (unsigned)ix < (unsigned)p.ws) m |= 1u << combo;
+    }
+    xinv[i] = ~m;
   }
-  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
   int off0, off1;
   frag_offsets(lane, off0, off1);
   const unsigned lds_x = lds_addr_of(Xb), lds_v = lds_addr_of(Vb);
   const int jchunks = p.Lp >> 5;
   const int nch = 4 * jchunks;
   // V staging role: 3 pieces per wave; piece it -> granule gidx = it*64 + lane -> key row jr, channel group cg
-  int vjr[3], vcg[3];
+  int vjr[3];
+  unsigned vcoff[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int gidx = (k * 4 + w) * 64 + lane;
     vjr[k] = gidx / 24;
     // bank swizzle: key rows j and j+4 (read by lane groups q and q+1 of one ds_read_b32) would hit the same 16 banks
     // (row stride 96 floats = 3 bank rows); rows with bit 2 set keep their granules swapped in blocks of 4
-    vcg[k] = (gidx - vjr[k] * 24) ^ (((vjr[k] >> 2) & 1) << 2);
+    vcoff[k] = (unsigned)((gidx - vjr[k] * 24) ^ (((vjr[k] >> 2) & 1) << 2)) * 16u;
+  }
+  unsigned ws_m;
+  int ws_l;
+  {   // x / ws for x < 2^32 (se_device.h udiv_magic), divisor uniform
+    int ll = 0;
+    while ((1u << ll) < (unsigned)p.ws) ++ll;
+    ws_l = ll;
+    ws_m = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << ll) - (unsigned)p.ws)) / (unsigned)p.ws + 1);
   }
 
   auto stage = [&](int ch, int buf) {
     const int combo = ch / jchunks, jc = ch - combo * jchunks;      // uniform
     const int a = combo >> 1, bb = combo & 1;
     const unsigned xdst = lds_x + buf * XBYTES, vdst = lds_v + buf * VBYTES;
+    const unsigned xdelta = (unsigned)((jc * 32 - (a * p.ws + bb) * p.Lp) * 4);      // uniform
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int iy = (ryx[i] >> 16) - a, ix = (ryx[i] & 0xffff) - bb;
-      const bool ok = ((unsigned)iy < (unsigned)p.hs) & ((unsigned)ix < (unsigned)p.ws);
-      const float* g = p.S + ((size_t)((unsigned)(b * p.L + iy * p.ws + ix)) * p.Lp + jc * 32 + s_log * 4);
-      g = ok ? g : p.zeros;
-      glds16(g, xdst + (i * 4 + w) * 1024);
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)xinv[i], combo, 1);      // all ones: outside -> zeros
+      bufdma16((xoff[i] + xdelta) | m, rs_S, xdst + (i * 4 + w) * 1024);
     }
     // V tile: key j -> pixel (2jy + py + 2a, 2jx + px + 2bb), 96 channels = 24 granules
+    const unsigned vbase = (unsigned)(((py + 2 * a) * p.w + px + 2 * bb) * 384);        // uniform
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int j = jc * 32 + vjr[k];
-      const int jy = j / p.ws, jx = j - jy * p.ws;
-      const float* g = p.x + ((size_t)((unsigned)((b * p.h + 2 * jy + py + 2 * a) * p.w + 2 * jx + px + 2 * bb)) * 96 + vcg[k] * 4);
-      g = j < p.L ? g : p.zeros;
-      glds16(g, vdst + (k * 4 + w) * 1024);
+      const int jy = (int)udiv_magic((unsigned)j, ws_m, ws_l), jx = j - jy * p.ws;
+      const unsigned off = (unsigned)(__mul24(jy, p.w) + jx) * 768u + vbase + vcoff[k];
+      bufdma16(j < p.L ? off : 0x80000000u, rs_x, vdst + (k * 4 + w) * 1024);
     }
   };
 
