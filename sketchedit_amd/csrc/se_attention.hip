@@ -58,17 +58,20 @@ __global__ __launch_bounds__(256) void att_score_kernel(const AttParams p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z;
   const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
-  // element offset of the patch origin of a query / key row, or -1
-  auto origin = [&](int i) {
-    if (i >= p.L) return -1;
+  // byte offset of the patch origin of a query / key row inside THIS image, or an out-of-range offset: both
+  // operands are staged through buffer resources (hardware zero fill, one VALU add per granule; se_gconv.hip)
+  auto origin = [&](int i) -> unsigned {
+    if (i >= p.L) return 0x80000000u;
     const int py = i / p.ws, px = i - py * p.ws;
-    return ((b * p.h + 2 * py) * p.w + 2 * px) * 96;
+    return (unsigned)(((2 * py) * p.w + 2 * px) * 384);
   };
-  int qo[NX], ko[NW];
+  const se_i32x4 rs_q = make_rsrc(p.x + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
+  const se_i32x4 rs_k = make_rsrc(p.xn + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
+  unsigned qo[NX], ko[NW];
 #pragma unroll
   for (int i = 0; i < NX; ++i) qo[i] = origin(q0 + (i * 4 + w) * 8 + (lane >> 3));
 #pragma unroll
-  for (int j = 0; j < NW; ++j) ko[j] = (j * 4 + w) < NT * 2 ? origin(k0 + (j * 4 + w) * 8 + (lane >> 3)) : -1;
+  for (int j = 0; j < NW; ++j) ko[j] = (j * 4 + w) < NT * 2 ? origin(k0 + (j * 4 + w) * 8 + (lane >> 3)) : 0x80000000u;
 
   const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
   int off0, off1;
@@ -78,18 +81,14 @@ __global__ __launch_bounds__(256) void att_score_kernel(const AttParams p) {
   auto stage = [&](int ch, int buf) {
     const int gi = ch * 8 + s_log;                 // granule of the 16 taps x 24 channel-groups
     const int tap = (gi * 2731) >> 16, cg = gi - tap * 24;      // gi / 24 for gi < 4096
-    const int doff = ((tap >> 2) * p.w + (tap & 3)) * 96 + cg * 4;
+    const unsigned doff = (unsigned)((__mul24(tap >> 2, p.w) + (tap & 3)) * 384 + cg * 16);
     const unsigned xdst = lds_x + buf * XBYTES, wdst = lds_w + buf * WBYTES;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const float* g = qo[i] >= 0 ? p.x + (qo[i] + doff) : p.zeros;
-      glds16(g, xdst + (i * 4 + w) * 1024);
-    }
+    for (int i = 0; i < NX; ++i) bufdma16(qo[i] + doff, rs_q, xdst + (i * 4 + w) * 1024);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int rbk = j * 4 + w;
-      const float* g = ko[j] >= 0 ? p.xn + (ko[j] + doff) : p.zeros;
-      if (rbk < NT * 2) glds16(g, wdst + rbk * 1024);
+      if (rbk < NT * 2) bufdma16(ko[j] + doff, rs_k, wdst + rbk * 1024);
     }
   };
 
