@@ -74,6 +74,13 @@ int se_inference(se_ctx* ctx, void* stream, const float* image, const float* ske
                  float* mask_out, float* hard_out, float* maskim_out, float* coarse_out, float* fine_out,
                  void* workspace, size_t workspace_bytes, int B, int H, int W, int flags);
 
+/* Output quantisation of test.py:25-27 on the device: rgb_out (B,H,W,3) uint8 = trunc((composed + 1) / 2 * 255)
+ * in the HWC order test.py:35 transposes to, mask_u8_out (B,H,W) uint8 = trunc(mask * 255); same fp32 operation
+ * order as the reference's tensor expressions, no clamp (as test.py; demo.py:62 clamps -- a [-1,1] input cannot
+ * leave [0,255] either way).  Either output may be NULL.  A 4x smaller device-to-host copy for the caller. */
+int se_quantize_u8(se_ctx* ctx, void* stream, const float* composed, const float* mask, unsigned char* rgb_out,
+                   unsigned char* mask_u8_out, int B, int H, int W);
+
 /* ---- measurement support (no reference counterpart; used by bench.py) ----------------------------
  * se_profile_enable(ctx, 1): wrap every kernel launch of subsequent forwards in a pair of HIP events
  * recorded on the launch stream; se_profile_report synchronises the device and writes a JSON array

@@ -23,7 +23,7 @@ FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TR
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
            "se_workspace_bytes", "se_netM_forward", "se_netG_forward", "se_inference", "se_gated_conv2d",
-           "se_attention", "se_profile_enable", "se_profile_report"]
+           "se_attention", "se_quantize_u8", "se_profile_enable", "se_profile_report"]
 
 
 class SketchEditHipError(RuntimeError):
@@ -84,6 +84,8 @@ def load_library():
         lib.se_gated_conv2d.restype = ci
         lib.se_attention.argtypes = [vp, vp, c_f, c_f, c_f, c_f, ci, ci, ci]
         lib.se_attention.restype = ci
+        lib.se_quantize_u8.argtypes = [vp, vp, c_f, c_f, vp, vp, ci, ci, ci]
+        lib.se_quantize_u8.restype = ci
         lib.se_profile_enable.argtypes = [vp, ci]
         lib.se_profile_enable.restype = ci
         lib.se_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
@@ -274,6 +276,17 @@ class Engine:
                                     acode, int(upsample)):
             self._err("se_gated_conv2d")
         return y
+
+    def quantize_u8(self, composed, mask):
+        """test.py:25-27 on the device: ((composed+1)/2*255) -> uint8 (B,H,W,3) RGB, (mask*255) -> uint8 (B,H,W)."""
+        import torch
+        _check_dev(composed, mask)
+        B, _, H, W = composed.shape
+        rgb = torch.empty((B, H, W, 3), dtype=torch.uint8, device=composed.device)
+        m8 = torch.empty((B, H, W), dtype=torch.uint8, device=composed.device)
+        if self.lib.se_quantize_u8(self.h, self._stream(), _ptr(composed), _ptr(mask), _ptr(rgb), _ptr(m8), B, H, W):
+            self._err("se_quantize_u8")
+        return rgb, m8
 
     def attention(self, x, mask_full, want_similar=False):
         import torch

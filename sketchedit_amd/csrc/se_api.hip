@@ -774,6 +774,19 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   return plan_netG(c, image, image, hard, hard, sketch, coarse_out, fine_out, mask_out, composed_out, B, H, W, flags);
 }
 
+// test.py:25-27 on the device
+int se_quantize_u8(se_ctx* c, void* stream, const float* composed, const float* mask, unsigned char* rgb_out,
+                   unsigned char* mask_u8_out, int B, int H, int W) {
+  if (!c) return 1;
+  if (check_dims(c, B, H, W)) return 1;
+  if ((rgb_out && !composed) || (mask_u8_out && !mask)) return fail(c, "null pointer argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  set_profiler(&c->prof);
+  HIPCHK(c, launch_quantize_u8(composed, mask, rgb_out, mask_u8_out, B, H, W, (hipStream_t)stream));
+  return 0;
+}
+
 // ---- measurement support (bench.py): per-kernel HIP-event timing ---------------------------------
 int se_profile_enable(se_ctx* c, int on) {
   if (!c) return 1;

@@ -130,6 +130,9 @@ hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, con
                          hipStream_t st);
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st);
+// test.py:25-27 output quantisation: composed NCHW (B,3,H,W) -> rgb HWC uint8, mask (B,1,H,W) -> uint8; W % 4 == 0
+hipError_t launch_quantize_u8(const float* composed, const float* mask, unsigned char* rgb, unsigned char* m8, int B, int H,
+                              int W, hipStream_t st);
 // column reduce over pixels: x [B][HW][C] -> out [B][C].  op 0 max, 1 mean, 2 rsqrt(sum(x^2)+1e-8)
 hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st);
 static const int COLREDUCE_SPLITS = 32;

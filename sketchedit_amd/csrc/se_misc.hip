@@ -208,6 +208,43 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
   const int c = bc % C, b = bc / C;
   dst[idx] = src[((long)b * HW + rem) * Cs + c];
 }
+// ---- output quantisation (test.py:25-27): 4 consecutive pixels per thread, 12 + 4 output bytes
+__global__ void quantize_u8_kernel(const float* __restrict__ comp, const float* __restrict__ mask,
+                                   unsigned char* __restrict__ rgb, unsigned char* __restrict__ m8, int B, int HW) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;      // group of 4 pixels
+  const long nq = (long)B * HW / 4;
+  if (q >= nq) return;
+  const long pix = q * 4;
+  const int b = (int)(pix / HW);
+  const long in = pix - (long)b * HW;
+  if (rgb) {
+    unsigned char o[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 v = *(const float4*)(comp + ((long)b * 3 + c) * HW + in);
+      const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i * 3 + c] = (unsigned char)(int)(((f[i] + 1.f) * 0.5f) * 255.f);   // (x+1)/2*255, truncated
+    }
+    unsigned* dst = (unsigned*)(rgb + pix * 3);
+    dst[0] = o[0] | (o[1] << 8) | (o[2] << 16) | ((unsigned)o[3] << 24);
+    dst[1] = o[4] | (o[5] << 8) | (o[6] << 16) | ((unsigned)o[7] << 24);
+    dst[2] = o[8] | (o[9] << 8) | (o[10] << 16) | ((unsigned)o[11] << 24);
+  }
+  if (m8) {
+    const float4 v = *(const float4*)(mask + pix);
+    *(unsigned*)(m8 + pix) = (unsigned)(unsigned char)(int)(v.x * 255.f) | ((unsigned)(unsigned char)(int)(v.y * 255.f) << 8) |
+                             ((unsigned)(unsigned char)(int)(v.z * 255.f) << 16) | ((unsigned)(unsigned char)(int)(v.w * 255.f) << 24);
+  }
+}
+hipError_t launch_quantize_u8(const float* composed, const float* mask, unsigned char* rgb, unsigned char* m8, int B, int H,
+                              int W, hipStream_t st) {
+  const long nq = (long)B * H * W / 4;
+  ProfScope ps_(st, PL_LAYOUT);
+  hipLaunchKernelGGL(quantize_u8_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, composed, mask, rgb, m8, B, H * W);
+  return hipGetLastError();
+}
+
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st) {
   const long n = (long)B * C * H * W;
   ProfScope ps_(st, PL_LAYOUT);

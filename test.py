@@ -14,11 +14,11 @@ cv2.imwrite(output[:, :, ::-1]) stores RGB order on disk, as Image.fromarray(out
 import os
 import sys
 
-import numpy as np
 import torch
 from PIL import Image
 
 from sketchedit_amd import data, models
+from sketchedit_amd._lib import shared_engine
 from sketchedit_amd.options.test_options import TestOptions
 
 
@@ -43,12 +43,14 @@ def main(argv=None):
             break
         with torch.no_grad():
             generated, mask = model(data_i, mode="inference")
-        mask = (mask * 255).cpu().numpy().astype(np.uint8)[:, 0]
-        generated = ((generated + 1) / 2 * 255).cpu().numpy().astype(np.uint8)   # no clamp, as test.py:26-27
+        # (x+1)/2*255 and mask*255 -> uint8 (no clamp, as test.py:26-27) on the device, already HWC: the D2H copy is
+        # a quarter of the fp32 tensors'
+        rgb, m8 = shared_engine(generated.device.index or 0).quantize_u8(generated.contiguous(), mask.contiguous())
+        generated, mask = rgb.cpu().numpy(), m8.cpu().numpy()
         for b in range(generated.shape[0]):
             path = data_i["path"][b]
             print("process image... %s" % path)
-            Image.fromarray(generated[b].transpose(1, 2, 0)).save(os.path.join(opt.output_dir, path))
+            Image.fromarray(generated[b]).save(os.path.join(opt.output_dir, path))
             if getattr(opt, "output_mask_dir", None) is not None:
                 Image.fromarray(mask[b]).save(os.path.join(opt.output_mask_dir, path))
 

@@ -115,6 +115,27 @@ def test_concurrent_callers(model):
     assert not errs, errs
 
 
+def test_quantize_u8_matches_test_py_expression(model):
+    """se_quantize_u8 == ((x+1)/2*255).astype(uint8) / (mask*255).astype(uint8) of test.py:25-27, bit for bit,
+    on real forward outputs and on the edge values -1, 1, 0 and 1-eps."""
+    from sketchedit_amd import synth
+    from sketchedit_amd._lib import shared_engine
+    img, sk = synth.make_inputs(2, 64, 72, seed=77)
+    ci, cs = torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda()
+    with torch.no_grad():
+        comp, mask = model({"image": ci, "mask": cs}, mode="inference")
+    comp = comp.clone()
+    comp[0, :, 0, :4] = torch.tensor([-1.0, 1.0, 0.0, 0.99999994], device="cuda")
+    mask = mask.clone()
+    mask[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 0.5, 0.99999994], device="cuda")
+    rgb, m8 = shared_engine(0).quantize_u8(comp.contiguous(), mask.contiguous())
+    want_rgb = ((comp + 1) / 2 * 255).cpu().numpy().astype(np.uint8).transpose(0, 2, 3, 1)
+    want_m = (mask * 255).cpu().numpy().astype(np.uint8)[:, 0]
+    assert rgb.dtype == torch.uint8 and tuple(rgb.shape) == (2, 64, 72, 3)
+    assert np.array_equal(rgb.cpu().numpy(), want_rgb)
+    assert np.array_equal(m8.cpu().numpy(), want_m)
+
+
 def test_test_py_script_end_to_end(tmp_path):
     """The reference's entry point: test.py with a test_celeb.sh-style command line, PNG in -> PNG out."""
     import importlib.util
