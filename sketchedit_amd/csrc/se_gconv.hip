@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       // DMA of the next chunk flies under the MFMAs, one piece per MFMA step
       const bool more = ch + 1 < p.nch;
       if (more) fast_head(ch + 1);
-      constexpr int SLOTS = 2 * NT, PER = (NPIECE + SLOTS - 1) / SLOTS;
+      // ... all within the first k-half of the chunk, so the youngest piece still has half a chunk of MFMAs to land
+      constexpr int SLOTS = NT, PER = (NPIECE + SLOTS - 1) / SLOTS;
       mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, [&](int slot) {
         if (more) {
 #pragma unroll
