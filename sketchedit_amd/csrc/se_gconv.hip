@@ -279,6 +279,8 @@ static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label
                           : launch_gconv_f<NT, PT, MIXED, WPS, false>(p, st, label);
 }
 
+// (A 3-stage LDS ring for the narrow MIXED shapes -- two chunks of DMA in flight, exact vmcnt waits -- was measured
+// and is slower: 66 KiB of LDS leave two instead of three workgroups per CU, N48 2.91 -> 3.38 ms.)
 // Tile shapes.  variant 0 is the default; SE_GCONV_VARIANT_<cfg>=k (environment) selects another one for
 // tuning sweeps.  Shapes with LDS <= 80 KiB and <= 256 registers run two workgroups per CU, so the staging
 // code, LDS-read latency and epilogue of one overlap the MFMAs of the other.
