@@ -8,7 +8,8 @@
 One "step" = one pass of EditLine2Model.forward(mode='inference') (netM -> threshold -> netG ->
 composite) over one synthetic batch per GPU: BASELINE.json config 2, 256x256, batch 32, fp32, inputs
 resident in HBM.  With N > 1 every rank runs its own batch shard (weak scaling, B per GPU fixed) and the
-(B,3,H,W) composites + (B,1,H,W) masks are all-gathered over RCCL inside the timed step.
+(B,3,H,W) composites + (B,1,H,W) masks are all-gathered over RCCL inside the timed region (side stream, under the
+next step's forward; every step's gather is complete before the closing fence).
 Rank 0 prints ONE JSON line (metric images/sec = N*B*K / max-over-ranks time).
 
 Extra objects in the line:
@@ -79,6 +80,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (test aid)")
     ap.add_argument("--check-gather", action="store_true", help="rank 0 verifies the gathered outputs (test aid)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather on the compute stream instead of a side stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,23 +112,56 @@ def main():
     img_h, sk_h = synth.make_inputs(B, S, S, seed=1234, first_index=rank * B)   # shard = rows of the global batch
     img = torch.from_numpy(img_h).to(dev)
     sk = torch.from_numpy(sk_h).to(dev)
-    out = {"composed": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
-           "mask": torch.empty((B, 1, S, S), dtype=torch.float32, device=dev)}
-    gathered = {}
+    # Outputs are double-buffered: for N > 1 the all-gather of step k runs on a side stream under the forward of step
+    # k+1 (the forward has no exchange inside; xGMI traffic and MFMA work do not compete).
+    def new_out():
+        return {"composed": torch.empty((B, 3, S, S), dtype=torch.float32, device=dev),
+                "mask": torch.empty((B, 1, S, S), dtype=torch.float32, device=dev)}
+    overlap = world > 1 and not args.no_overlap
+    outs = [new_out(), new_out()] if overlap else [new_out()]
+    out = outs[0]
+    gathered_sets = []
     if world > 1:
-        gathered["composed"] = torch.empty((world * B, 3, S, S), dtype=torch.float32, device=dev)
-        gathered["mask"] = torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev)
+        for _ in outs:
+            gathered_sets.append({"composed": torch.empty((world * B, 3, S, S), dtype=torch.float32, device=dev),
+                                  "mask": torch.empty((world * B, 1, S, S), dtype=torch.float32, device=dev)})
+    gathered = gathered_sets[0] if gathered_sets else {}
+    comm_stream = torch.cuda.Stream(device=dev) if overlap else None
+    gather_done = [None, None]
+    state = {"i": 0, "last": 0}
+
+    def gather(o, g):
+        # the only exchange of the path: all-gather of the outputs
+        for k in ("composed", "mask"):
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(g[k], o[k])
+            else:              # gloo cannot all-gather device tensors: stage through the host (test aid only)
+                parts = [torch.empty(o[k].shape, dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, o[k].cpu())
+                g[k].copy_(torch.cat(parts, 0))
 
     def step():
-        eng.inference(img, sk, FLAGS, out=out)
-        if world > 1:      # the only exchange of the path: all-gather of the outputs
-            for k in ("composed", "mask"):
-                if args.backend == "nccl":
-                    dist.all_gather_into_tensor(gathered[k], out[k])
-                else:              # gloo cannot all-gather device tensors: stage through the host (test aid only)
-                    parts = [torch.empty(out[k].shape, dtype=torch.float32) for _ in range(world)]
-                    dist.all_gather(parts, out[k].cpu())
-                    gathered[k].copy_(torch.cat(parts, 0))
+        i = state["i"]
+        state["i"] = i + 1
+        if not overlap:
+            eng.inference(img, sk, FLAGS, out=outs[0])
+            if world > 1:
+                gather(outs[0], gathered_sets[0])
+            return
+        slot = i & 1
+        main = torch.cuda.current_stream(dev)
+        if gather_done[slot] is not None:          # the gather that last read this output buffer (step i-2)
+            main.wait_event(gather_done[slot])
+        eng.inference(img, sk, FLAGS, out=outs[slot])
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            gather(outs[slot], gathered_sets[slot])
+            done = torch.cuda.Event()
+            done.record(comm_stream)
+        gather_done[slot] = done
+        state["last"] = slot
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -148,6 +183,7 @@ def main():
         elapsed = float(t.item())
         if args.check_gather:
             # every rank finds its own rows in the gathered batch; rank 0 recomputes image 0 of rank 1's shard
+            out, gathered = outs[state["last"]], gathered_sets[state["last"]]
             ok = torch.equal(gathered["composed"][rank * B:(rank + 1) * B], out["composed"]) and \
                 torch.equal(gathered["mask"][rank * B:(rank + 1) * B], out["mask"])
             if rank == 0:
@@ -224,7 +260,7 @@ def main():
             "config": {"workload": "SketchEdit inference forward (netM+netG, use_cam, pool max) %dx%d batch %d per GPU, "
                                    "procedural weights" % (S, S, B),
                        "global_batch": world * B, "size": S, "per_gpu_batch": B,
-                       "collective": "all_gather(composed, mask)" if world > 1 else None},
+                       "collective": ("all_gather(composed, mask)" + (" on a side stream, under the next step's forward" if overlap else "")) if world > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
             "layers": ({r["layer"]: {"ms": round(r["total_ms"] / nprof, 4), "n": r["launches"] // nprof,
                                      "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)}

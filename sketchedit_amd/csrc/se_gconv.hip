@@ -308,10 +308,12 @@ hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
     case GC_N48:
       if (var == 1) return launch_gconv_t<3, 8, true, 1>(p, st, PL_GCONV_N48);
       if (var == 2) return launch_gconv_t<3, 4, true, 2>(p, st, PL_GCONV_N48);
+      if (var == 3) return launch_gconv_t<3, 1, true, 4>(p, st, PL_GCONV_N48);
       return launch_gconv_t<3, 2, true, 2>(p, st, PL_GCONV_N48);
     case GC_N24:
       if (var == 1) return launch_gconv_t<2, 8, true, 1>(p, st, PL_GCONV_N24);
       if (var == 2) return launch_gconv_t<2, 4, true, 2>(p, st, PL_GCONV_N24);
+      if (var == 3) return launch_gconv_t<2, 1, true, 4>(p, st, PL_GCONV_N24);
       return launch_gconv_t<2, 2, true, 2>(p, st, PL_GCONV_N24);
   }
   return hipErrorInvalidValue;
