@@ -175,24 +175,22 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       for (int b = 0; b < 2; ++b) of[a][b][j] = og[a][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // fold the finished position accumulators: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1].
-  // nu is compile-time (zero terms are not generated: 12 of 16 remain), the row factor At[a][xi] is a uniform float.
+  // xi and nu are compile-time in the unrolled loop: only the non-zero terms exist, as packed adds / fmas.
   // (fp32 MFMA and VALU do not overlap on a SIMD, so there is nothing to gain from a second accumulator set that
   // would let the fold run "under" the next position's MFMAs; one set saves 24 registers.)
+  float neg1 = -1.f;
+  asm volatile("" : "+v"(neg1));      // opaque multiplier: keeps a subtraction one packed fma (a plain -= becomes 4 v_sub)
   auto fold = [&](const f32x4 (&pf)[3], const f32x4 (&pg)[3], int xi, int nu, int j) {     // channel tile j
-    int by0 = xi < 3 ? 0x3f800000 : 0, by1 = xi == 0 ? 0 : (xi == 1 ? 0x3f800000 : (int)0xbf800000);
-    asm volatile("" : "+s"(by0), "+s"(by1));      // keep them scalar operands of v_pk_fma (no per-value code paths)
-    const float ay0 = __int_as_float(by0), ay1 = __int_as_float(by1);
-    if (nu < 3) {                       // At[0][nu] = 1
-      of[0][0][j] += pf[j] * ay0; og[0][0][j] += pg[j] * ay0;
-      of[1][0][j] += pf[j] * ay1; og[1][0][j] += pg[j] * ay1;
-    }
-    if (nu == 1) {                      // At[1][nu] = 1
-      of[0][1][j] += pf[j] * ay0; og[0][1][j] += pg[j] * ay0;
-      of[1][1][j] += pf[j] * ay1; og[1][1][j] += pg[j] * ay1;
-    } else if (nu >= 2) {               // At[1][nu] = -1
-      of[0][1][j] -= pf[j] * ay0; og[0][1][j] -= pg[j] * ay0;
-      of[1][1][j] -= pf[j] * ay1; og[1][1][j] -= pg[j] * ay1;
-    }
+    const int ay[2] = {xi < 3 ? 1 : 0, xi == 0 ? 0 : (xi == 1 ? 1 : -1)};      // At[a][xi]   (xi, nu compile-time:
+    const int ax[2] = {nu < 3 ? 1 : 0, nu == 0 ? 0 : (nu == 1 ? 1 : -1)};      // At[b][nu]    9 of 16 terms exist)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int c = ay[a] * ax[b];
+        if (c > 0) { of[a][b][j] += pf[j]; og[a][b][j] += pg[j]; }
+        else if (c < 0) { of[a][b][j] = pf[j] * neg1 + of[a][b][j]; og[a][b][j] = pg[j] * neg1 + og[a][b][j]; }
+      }
     // pin the sums here: in unrolled code hipcc would otherwise sink every fold to the end of the kernel and keep
     // all 16 position results alive (in scratch) until then
     asm volatile("" : "+v"(of[0][0][j]), "+v"(of[0][1][j]), "+v"(of[1][0][j]), "+v"(of[1][1][j]),
