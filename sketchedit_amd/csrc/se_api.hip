@@ -124,6 +124,7 @@ struct se_ctx {
   std::mutex mu;
   std::string err;
   std::map<std::string, Layer> G, M;
+  Layer wconv1_j4;          // G.wconv1 packed for a 4-channel input: with --joint_train_inp its guide channel is zero
   float* zeros = nullptr;   // zero page for out-of-bounds granules
   Arena arena;
   hipStream_t st = nullptr;
@@ -347,6 +348,14 @@ int pack_net_layer(se_ctx* c, Layer& L) {
   std::vector<int> m;
   if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
   else m = identity_map(d.cin);
+  if (std::string(d.name) == "wconv1" && d.cin == 5) {
+    // editline_g.py:132-133: with joint_train_inp the style branch sees guide * 0, so its first layer is a 4-channel
+    // conv (image*mask, mask) with the guide column of the weights dropped: K = 100 instead of 200 (NHWC8 padding)
+    Layer& J = c->wconv1_j4;
+    J.def = d; J.w = L.w; J.b = L.b; J.have_w = J.have_b = true;
+    const int rc = pack_layer(c, J, std::vector<int>{0, 1, 2, 4});
+    if (rc) return rc;
+  }
   return pack_layer(c, L, m);
 }
 
@@ -449,9 +458,12 @@ struct Plan {
   void free(Act& a) { c->arena.release(a.p); a.p = nullptr; }
   // gated conv layer: consumes (and releases, if `rel`) `in`
   Act conv(const char* name, Act& in, bool rel = true, const float* src1 = nullptr, int C1 = 0, int vec = 0) {
+    if (rc) return Act();
+    return conv_layer(net.at(name), in, rel, src1, C1, vec);
+  }
+  Act conv_layer(Layer& L, Act& in, bool rel = true, const float* src1 = nullptr, int C1 = 0, int vec = 0) {
     Act out;
     if (rc) return out;
-    Layer& L = net.at(name);
     int Ho = 0, Wo = 0;
     // dry pass to get shape
     bool dry = c->dry; c->dry = true;
@@ -466,8 +478,8 @@ struct Plan {
 };
 
 // encoder: conv1 (5x5) .. conv10_atrous; returns conv10 output, optionally keeps conv9's
-Act encoder(Plan& P, const std::string& p, Act& in, Act* keep9) {
-  Act x = P.conv((p + "1").c_str(), in);
+Act encoder(Plan& P, const std::string& p, Act& in, Act* keep9, Layer* first = nullptr) {
+  Act x = first ? P.conv_layer(*first, in) : P.conv((p + "1").c_str(), in);
   x = P.conv((p + "2_downsample").c_str(), x);
   x = P.conv((p + "3").c_str(), x);
   x = P.conv((p + "4_downsample").c_str(), x);
@@ -540,13 +552,14 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
               int flags) {
   Plan P(c, c->G, B);
   const int joint = (flags & SE_FLAG_JOINT_TRAIN_INP) ? 1 : 0;
-  Act cin = P.alloc(H, W, 8), sin = P.alloc(H, W, 8);
+  // joint_train_inp: the style input is packed without its (zero) guide channel and wconv1 runs as a 4-channel conv
+  Act cin = P.alloc(H, W, 8), sin = P.alloc(H, W, joint ? 4 : 8);
   if (P.rc) return P.rc;
   if (!c->dry)
     HIPCHK(c, launch_pack_g(x, x2, mask, mask2, guide, cin.p, sin.p, B, H, W, (flags & SE_FLAG_NO_MASK_CC) ? 1 : 0,
                             joint, c->st));
   Act xc = encoder(P, "conv", cin, nullptr);        // :138-147
-  Act xs = encoder(P, "wconv", sin, nullptr);       // :149-158
+  Act xs = encoder(P, "wconv", sin, nullptr, joint ? &c->wconv1_j4 : nullptr);       // :149-158
   // global pool of the style branch -> (B,96) vector, consumed as second (spatially constant) source
   Act part = P.alloc(1, COLREDUCE_SPLITS, 96), vec = P.alloc(1, 1, 96);
   if (P.rc) return P.rc;
@@ -661,6 +674,8 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_u) (void)hipFree(kv.second.d_u);
       if (kv.second.d_ub) (void)hipFree(kv.second.d_ub);
     }
+  if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
+  if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
   if (c->zeros) (void)hipFree(c->zeros);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
   delete c;
@@ -718,7 +733,7 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
   peak = c->arena.peak;
   c->arena.reset(nullptr, 0, true);
   plan_netG(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W,
-            SE_FLAG_USE_CAM | SE_FLAG_POOL_MAX | SE_FLAG_JOINT_TRAIN_INP);
+            SE_FLAG_USE_CAM | SE_FLAG_POOL_MAX);      // without joint_train_inp: the larger (8-channel) style input
   if (c->arena.peak > peak) peak = c->arena.peak;
   c->dry = false;
   return peak + ((size_t)B * H * W * 4 + 256);   // + hard-mask plane used by se_inference

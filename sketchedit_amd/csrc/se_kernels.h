@@ -124,7 +124,8 @@ hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st);
 // ---------------------------------------------------------------------------------------------
 // netM input: [image(3), sketch(1)] NCHW -> NHWC4
 hipError_t launch_pack_m(const float* image, const float* sketch, float* dst4, int B, int H, int W, hipStream_t st);
-// netG inputs: coarse NHWC8 = [x*(1-m) (3), guide, m, 0,0,0]; style NHWC8 = [x2*m2 (3) (or x2), g2, m2, 0,0,0]
+// netG inputs: coarse NHWC8 = [x*(1-m) (3), guide, m, 0,0,0]; style NHWC8 = [x2*m2 (3) (or x2), g2, m2, 0,0,0],
+// or with joint (guide * 0): style NHWC4 = [x2*m2 (3) (or x2), m2]
 hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
                          float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint,
                          hipStream_t st);

@@ -170,8 +170,13 @@ __global__ void pack_g_kernel(const float* __restrict__ x, const float* __restri
   s1 = (f32x4){m2, 0.f, 0.f, 0.f};
   *(f32x4*)(coarse8 + idx * 8) = c0;
   *(f32x4*)(coarse8 + idx * 8 + 4) = c1;
-  *(f32x4*)(style8 + idx * 8) = s0;
-  *(f32x4*)(style8 + idx * 8 + 4) = s1;
+  if (joint) {            // 4-channel style input: (x2*m2, m2) -- the guide channel is guide * 0 (editline_g.py:132-133)
+    s0[3] = m2;
+    *(f32x4*)(style8 + idx * 4) = s0;
+  } else {
+    *(f32x4*)(style8 + idx * 8) = s0;
+    *(f32x4*)(style8 + idx * 8 + 4) = s1;
+  }
 }
 hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
                          float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint,
