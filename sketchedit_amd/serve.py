@@ -1,0 +1,118 @@
+"""Serving helpers for the inference path: the per-request pre/post-processing of the reference's demo
+(/root/reference/demo.py:39-73, `process_image`) and a small dynamic batcher for concurrent callers
+(demo.py:120 runs Flask with threaded=True, i.e. concurrent forwards on one model object).
+
+No web framework here -- the Flask UI is out of scope; these are the pieces of it that touch the hot path.
+"""
+import threading
+import time
+
+import numpy as np
+
+
+def _to_tensors(img, mask):
+    """demo.py:40-56: RGB, sizes floored to multiples of 8, image to [-1, 1], mask > 0."""
+    import torch
+    img = img.convert("RGB")
+    w_raw, h_raw = img.size
+    h_t, w_t = h_raw // 8 * 8, w_raw // 8 * 8
+    if h_t < 16 or w_t < 16:
+        raise ValueError("image too small: %dx%d" % (w_raw, h_raw))
+    x = np.array(img.resize((w_t, h_t))).transpose((2, 0, 1))
+    m = np.array(mask.resize((w_t, h_t)))
+    if m.ndim == 3:
+        m = m[..., 0]
+    m = (torch.from_numpy(m.astype(np.float32)) > 0).float()
+    x = (torch.from_numpy(x.astype(np.float32)) / 255 - 0.5) / 0.5
+    return x[None], m[None, None], (w_raw, h_raw)
+
+
+def _to_image(generated, size_raw):
+    """demo.py:62-70: clamp, (x+1)/2*255, uint8, HWC, resize back to the request's size."""
+    import torch
+    from PIL import Image
+    g = torch.clamp(generated, -1, 1)
+    g = ((g + 1) / 2 * 255).cpu().numpy().astype(np.uint8)
+    return Image.fromarray(g[0].transpose((1, 2, 0))).resize(size_raw)
+
+
+def process_image(model, img, mask):
+    """One request, as demo.py:39-73 handles it: PIL image + PIL sketch/mask in, PIL result out."""
+    import torch
+    x, m, size_raw = _to_tensors(img, mask)
+    with torch.no_grad():
+        generated, _ = model({"image": x, "mask": m}, mode="inference")
+    return _to_image(generated, size_raw)
+
+
+class BatchingServer:
+    """Concurrent `submit(img, mask)` calls are grouped by working size and run as one forward per group
+    (up to `max_batch` requests, waiting at most `max_wait_s` for company).  The forward treats the images of a
+    batch independently, so a request's result does not depend on what it was batched with."""
+
+    def __init__(self, model, max_batch=32, max_wait_s=0.005):
+        self.model, self.max_batch, self.max_wait_s = model, max_batch, max_wait_s
+        self._lock = threading.Condition()
+        self._queue = []          # (x, m, size_raw, slot)
+        self._stop = False
+        self.batches = []         # sizes of the batches that were run (observability / tests)
+        self._worker = threading.Thread(target=self._run, daemon=True)
+        self._worker.start()
+
+    def submit(self, img, mask):
+        x, m, size_raw = _to_tensors(img, mask)
+        slot = {"done": threading.Event(), "out": None, "err": None}
+        with self._lock:
+            if self._stop:
+                raise RuntimeError("server is closed")
+            self._queue.append((x, m, size_raw, slot))
+            self._lock.notify()
+        slot["done"].wait()
+        if slot["err"] is not None:
+            raise slot["err"]
+        return slot["out"]
+
+    def close(self):
+        with self._lock:
+            self._stop = True
+            self._lock.notify()
+        self._worker.join()
+
+    def _take_group(self):
+        """Oldest request's size decides the group; wait briefly for more requests of that size."""
+        with self._lock:
+            while not self._queue and not self._stop:
+                self._lock.wait()
+            if not self._queue:
+                return None
+            shape = tuple(self._queue[0][0].shape)
+            deadline = time.monotonic() + self.max_wait_s
+            while sum(1 for q in self._queue if tuple(q[0].shape) == shape) < self.max_batch:
+                left = deadline - time.monotonic()
+                if left <= 0 or self._stop:
+                    break
+                self._lock.wait(left)
+            group = [q for q in self._queue if tuple(q[0].shape) == shape][:self.max_batch]
+            taken = {id(q) for q in group}       # (list.remove would compare the tensors inside the tuples)
+            self._queue = [q for q in self._queue if id(q) not in taken]
+            return group
+
+    def _run(self):
+        import torch
+        while True:
+            group = self._take_group()
+            if group is None:
+                return
+            try:
+                x = torch.cat([q[0] for q in group], 0)
+                m = torch.cat([q[1] for q in group], 0)
+                with torch.no_grad():
+                    generated, _ = self.model({"image": x, "mask": m}, mode="inference")
+                self.batches.append(len(group))
+                for i, q in enumerate(group):
+                    q[3]["out"] = _to_image(generated[i:i + 1], q[2])
+            except Exception as e:      # deliver the failure to every waiting caller
+                for q in group:
+                    q[3]["err"] = e
+            for q in group:
+                q[3]["done"].set()

@@ -136,6 +136,48 @@ def test_quantize_u8_matches_test_py_expression(model):
     assert np.array_equal(m8.cpu().numpy(), want_m)
 
 
+@pytest.mark.timeout(120)
+def test_serve_process_image_and_dynamic_batching(model):
+    """demo.py:39-73 equivalent: arbitrary request size -> multiples of 8 -> forward -> clamp/uint8 -> resize back;
+    concurrent submitters are batched (same results as one-by-one processing: images are independent)."""
+    import threading
+    from PIL import Image
+    from sketchedit_amd import serve
+    rng = np.random.RandomState(3)
+    reqs = []
+    for (w, h) in [(70, 67), (70, 67), (70, 67), (96, 64), (70, 67)]:
+        img = Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8))
+        sk = Image.fromarray(((rng.rand(h, w) < 0.01) * 255).astype(np.uint8))
+        reqs.append((img, sk))
+    single = [serve.process_image(model, img, sk) for img, sk in reqs]
+    for (img, _), out in zip(reqs, single):
+        assert out.size == img.size and out.mode == "RGB"
+    # the steps of demo.py written out by hand for request 0
+    img, sk = reqs[0]
+    x = (torch.from_numpy(np.array(img.resize((64, 64))).transpose(2, 0, 1).astype(np.float32)) / 255 - 0.5) / 0.5
+    m = (torch.from_numpy(np.array(sk.resize((64, 64))).astype(np.float32)) > 0).float()
+    with torch.no_grad():
+        g, _ = model({"image": x[None], "mask": m[None, None]}, mode="inference")
+    g = ((torch.clamp(g, -1, 1) + 1) / 2 * 255).cpu().numpy().astype(np.uint8)[0].transpose(1, 2, 0)
+    assert np.array_equal(np.asarray(Image.fromarray(g).resize(img.size)), np.asarray(single[0]))
+    srv = serve.BatchingServer(model, max_batch=8, max_wait_s=0.2)
+    outs = [None] * len(reqs)
+
+    def worker(i):
+        outs[i] = srv.submit(*reqs[i])
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(reqs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    srv.close()
+    for a, b in zip(single, outs):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert sum(srv.batches) == len(reqs) and max(srv.batches) >= 2     # the four 70x67 requests shared forwards
+    with pytest.raises(ValueError):
+        serve.process_image(model, Image.new("RGB", (12, 40)), Image.new("L", (12, 40)))
+
+
 def test_test_py_script_end_to_end(tmp_path):
     """The reference's entry point: test.py with a test_celeb.sh-style command line, PNG in -> PNG out."""
     import importlib.util

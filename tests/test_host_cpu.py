@@ -175,3 +175,49 @@ def test_sharded_inference_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARD_OK" in outs[0]
+
+
+@pytest.mark.timeout(60)
+def test_batching_server_groups_by_size_and_preserves_results():
+    """sketchedit_amd/serve.py (demo.py:39-73 + threaded callers) with a stand-in model: requests of one working size
+    share a forward, results equal one-by-one processing, a failing forward reaches every waiting caller."""
+    import threading
+    import time
+    import torch
+    from PIL import Image
+    from sketchedit_amd import serve
+
+    class Fake:
+        def __call__(self, data, mode):
+            assert mode == "inference"
+            time.sleep(0.01)
+            return data["image"] * 0.5, data["mask"]
+
+    rng = np.random.RandomState(3)
+    reqs = []
+    for (w, h) in [(70, 67), (70, 67), (70, 67), (96, 64), (70, 67)]:
+        reqs.append((Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)),
+                     Image.fromarray(((rng.rand(h, w) < 0.01) * 255).astype(np.uint8))))
+    single = [serve.process_image(Fake(), i, s) for i, s in reqs]
+    assert all(o.size == i.size for o, (i, _) in zip(single, reqs))
+    srv = serve.BatchingServer(Fake(), max_batch=8, max_wait_s=0.3)
+    outs = [None] * len(reqs)
+
+    def worker(k):
+        outs[k] = srv.submit(*reqs[k])
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(len(reqs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    srv.close()
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(single, outs))
+    assert sorted(srv.batches) == [1, 4]
+
+    class Broken:
+        def __call__(self, data, mode):
+            raise RuntimeError("boom")
+    srv = serve.BatchingServer(Broken(), max_batch=4, max_wait_s=0.01)
+    with pytest.raises(RuntimeError, match="boom"):
+        srv.submit(*reqs[0])
+    srv.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        srv.submit(*reqs[0])
