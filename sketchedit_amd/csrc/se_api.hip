@@ -380,7 +380,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.src1 = src1; wp.src1_vec = src1_vec;
-    wp.upk = L.d_u; wp.bias = L.d_b; wp.dst = dst; wp.zeros = c->zeros;
+    wp.upk = L.d_u; wp.bias = L.d_b; wp.dst = dst;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
@@ -397,7 +397,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
       (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
-    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst; wp.zeros = c->zeros;
+    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
@@ -620,7 +620,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
     AttParams a;
     memset(&a, 0, sizeof a);
     a.x = x.p; a.rn = rn.p; a.xn = xn.p; a.hard = mask_full; a.valid = valid.p; a.S = S.p; a.out = out.p;
-    a.zeros = c->zeros; a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.L = L; a.Lp = Lp;
+    a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.L = L; a.Lp = Lp;
     a.scale = 10.f; a.th = 0.1f;                        // editline_g.py:35-38
     HIPCHK(c, launch_attention(a, c->st));
     if (similar_nchw) {

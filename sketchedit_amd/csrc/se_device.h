@@ -69,7 +69,6 @@ DEVFN unsigned lds_addr_of(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-DEVFN float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // nn.ELU(), alpha 1 (accurate form)
 DEVFN float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // epilogue forms on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1-2 ulp): absolute error ~1e-7,
 // three orders below the 1e-3 parity budget

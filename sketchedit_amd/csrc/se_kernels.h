@@ -1,5 +1,5 @@
 // Internal (C++) interface between the host-side forward plan (se_api.hip) and the
-// gfx950 kernels (se_kernels.hip).  Not part of the C-ABI.
+// gfx950 kernels (se_gconv.hip, se_wino.hip, se_wino48.hip, se_attention.hip, se_misc.hip).  Not part of the C-ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -30,7 +30,7 @@ void set_launch_cost(double flops, double bytes, const char* name = nullptr);   
 // Gather-GEMM gated convolution (the hot kernel).
 //   D[n][p] = sum_k Wp[n][k] * X[p][k]   n: packed output channels, p: output pixels,
 //   k: flattened (tap, channel) in 32-float chunks.  X rows are gathered on the fly from
-//   one or two NHWC sources (im2col-free); Wp is packed on the host (se_pack.cpp).
+//   one or two NHWC sources (im2col-free); Wp is packed on the host (se_api.hip pack_layer).
 // ---------------------------------------------------------------------------------------------
 struct GConvParams {
   const float* src0;   // NHWC [B][Hin][Win][C0]
@@ -87,7 +87,6 @@ struct WinoParams {
   const float* upk;    // [16 positions][3 or 6 chunks][192 packed rows][32]: G g G^T, LDS image (pre-swizzled)
   const float* bias;   // [192] packed-row order (features, then gates)
   float* dst;          // NHWC [B][h][w][96]
-  const float* zeros;
   int B, h, w, d;      // dilation d; h % 2d == 0 and w % 2d == 0
   int th, tw;          // tile grid h/2 x w/2
   int total_tiles;     // B*th*tw
@@ -149,7 +148,6 @@ struct AttParams {
   float* valid;        // [B][Lp]  workspace: key validity {0,1}
   float* S;            // [B][L][Lp] workspace: scores, query-major
   float* out;          // NHWC [B][h][w][96]
-  const float* zeros;
   int B, h, w, hs, ws, L, Lp;
   float scale;         // softmax scale (10)
   float th;            // validity threshold (0.1)
