@@ -271,6 +271,29 @@ def test_errors(eng_w):
         eng_w.load_state_dict("G", {"conv1.weight": np.zeros((48, 4, 5, 5), np.float32)})
 
 
+SMALL_SIZES = [(1, 16, 16), (2, 24, 16), (1, 16, 40), (3, 32, 32), (1, 104, 88)]
+
+
+@pytest.mark.parametrize("case", SMALL_SIZES, ids=["%dx%dx%d" % c for c in SMALL_SIZES])
+def test_small_and_odd_sizes_vs_oracle(eng_w, case):
+    """Minimum size (16x16: one attention key), non-square multiples of 8 whose quarter-resolution grids are odd
+    (Winograd kernels fall back per layer) and tile counts that do not fill a workgroup -- end to end vs the oracle."""
+    from oracle import sketchedit_oracle as O
+    B, H, W = case
+    img, sk = synth.make_inputs(B, H, W, seed=5)
+    WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
+    ref = O.inference(WM, WG, img, sk)
+    r = eng_w.inference(_cuda(img), _cuda(sk), FLAGS, visualize=True)
+    assert _md(r["mask"], ref["mask"]) < TOL_E2E
+    hard = ref["hard_mask"].cuda()
+    ci, cs = _cuda(img), _cuda(sk)
+    coarse, fine = eng_w.netG(ci, ci, hard, hard, cs, FLAGS)
+    assert _md(coarse, ref["coarse"]) < TOL_E2E
+    assert _md(fine, ref["fine"]) < TOL_E2E
+    if int((r["hard"].cpu() != ref["hard_mask"]).sum()) == 0:
+        assert _md(r["composed"], ref["composed"]) < TOL_E2E
+
+
 def test_512_parity_vs_oracle(eng_w):
     """BASELINE config 3 resolution (512x512, L = 3969 attention keys): one image against the oracle."""
     from oracle import sketchedit_oracle as O
