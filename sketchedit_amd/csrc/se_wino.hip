@@ -34,7 +34,10 @@
 //      earlier), so the MFMA stream continues straight across the barrier.
 //   4. Granules and W DMA are waited for (one vmcnt(0)) half an iteration after they were issued; the W tile goes
 //      to a 4-slot ring two barriers ahead of its reader so that this one conservative wait is enough.
-// Per-launch time 200 -> 166 us (B=32, 64x64; 115 TF/s executed = 73 % of the fp32 MFMA peak, 258 TF/s in direct-
+// (Also measured: all VALU work right behind the barrier, where both waves of a SIMD could overlap their latency-
+// bound VALU phases, with the vector-memory instructions in the first four groups: no gain -- the memory queue
+// stalls come back.)
+// Per-launch time 200 -> 164 us (B=32, 64x64; 115 TF/s executed = 73 % of the fp32 MFMA peak, 258 TF/s in direct-
 // convolution terms).  Tried and NOT faster: a ping-pong split (waves 0-3 / 4-7 one phase apart, two barriers per
 // iteration: 237 us), two 4-wave workgroups per CU, 16-wave workgroups with an LDS gate exchange, raw granules in
 // registers, an "LDS patch" form without global loads in the loop, two positions per barrier.
