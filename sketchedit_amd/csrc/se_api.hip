@@ -159,6 +159,8 @@ bool wino_eligible_layer(const LayerDef& d);
 int pack_wino(se_ctx* c, Layer& L);
 bool wino48_eligible_layer(const LayerDef& d);
 int pack_wino48(se_ctx* c, Layer& L);
+bool winoup_eligible_layer(const LayerDef& d);
+int pack_winoup(se_ctx* c, Layer& L);
 
 int xcd_remap_enabled() {      // SE_XCD_REMAP=0 switches the XCD-aware tile order off (A/B measurements)
   static const int v = getenv("SE_XCD_REMAP") ? atoi(getenv("SE_XCD_REMAP")) : 1;
@@ -242,6 +244,7 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   L.packed = true;
   if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
+  if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
   return 0;
 }
 
@@ -318,6 +321,56 @@ int pack_wino48(se_ctx* c, Layer& L) {
   return 0;
 }
 
+// gen_deconv 96 -> 96 (se_wino_up.hip): per output parity class the pre-summed 2x2 weights g (pack_layer) are
+// transformed with G = [1 0; 1 1; 0 1]: U = G g G^T (3x3 positions), 27 iterations = 9 positions x 3 chunks of 32
+// channels, rows in the MIXED order.
+bool winoup_eligible_layer(const LayerDef& d) {
+  return d.k == 3 && d.stride == 1 && d.up && d.cin == 96 && d.cout == 96 && d.act != ACT_NONE;
+}
+int pack_winoup(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const float Gm[3][2] = {{1.f, 0.f}, {1.f, 1.f}, {0.f, 1.f}};
+  const int NP = 96;
+  std::vector<float> img((size_t)4 * 27 * NP * 32, 0.f), bias(NP, 0.f);
+  auto lo = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2); };
+  auto hi = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2); };
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    for (int n = 0; n < NP; ++n) {
+      const int t = n / 16, r = n % 16;
+      const int oc = r < 8 ? t * 8 + r : 48 + t * 8 + (r - 8);
+      bias[n] = L.b[oc];
+      for (int ic = 0; ic < 96; ++ic) {
+        float g[2][2];
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b) {
+            float v = 0.f;
+            for (int ky = lo(py, a); ky <= hi(py, a); ++ky)
+              for (int kx = lo(px, b); kx <= hi(px, b); ++kx) v += L.w[(((size_t)oc * d.cin + ic) * 3 + ky) * 3 + kx];
+            g[a][b] = v;
+          }
+        for (int xi = 0; xi < 3; ++xi)
+          for (int nu = 0; nu < 3; ++nu) {
+            float u = 0.f;
+            for (int a = 0; a < 2; ++a)
+              for (int b = 0; b < 2; ++b) u += Gm[xi][a] * Gm[nu][b] * g[a][b];
+            const int it = (xi * 3 + nu) * 3 + ic / 32, kin = ic % 32;
+            const int s_ = kin / 4, e = kin % 4;
+            const int ps = s_ ^ ((n >> 1) & 7);
+            img[(((size_t)cls * 27 + it) * NP + n) * 32 + ps * 4 + e] = u;
+          }
+      }
+    }
+  }
+  if (L.d_u) (void)hipFree(L.d_u);
+  if (L.d_ub) (void)hipFree(L.d_ub);
+  HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_ub, bias.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_ub, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
 int pack_small(se_ctx* c, Layer& L) {
   // raw 3x3 conv 12 -> cout: [cout][9][12]
   const LayerDef& d = L.def;
@@ -376,7 +429,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   const bool wino_src_ok = (!src1 && C0 == 96 && d.cin == 96) || (src1 && C0 == 96 && C1 == 96 && d.cin == 192);
   // the kernel addresses a source through 32-bit byte offsets (96 floats per pixel)
   const bool wino_addr_ok = (long long)B * Hin * Win * 384 < (1ll << 31);
-  if (use_wino && L.d_u && wino_src_ok && wino_addr_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+  if (use_wino && !d.up && L.d_u && wino_src_ok && wino_addr_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.src1 = src1; wp.src1_vec = src1_vec;
@@ -393,7 +446,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     return 0;
   }
   static const bool use_wino48 = !(getenv("SE_WINOGRAD48") && atoi(getenv("SE_WINOGRAD48")) == 0);
-  if (use_wino && use_wino48 && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && (long long)B * Hin * Win * 192 < (1ll << 31) &&
+  if (use_wino && use_wino48 && !d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && (long long)B * Hin * Win * 192 < (1ll << 31) &&
       (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
@@ -406,6 +459,23 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
     set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 48, d.name);
     HIPCHK(c, launch_wino48(wp, c->st));
+    return 0;
+  }
+  static const bool use_winoup = !(getenv("SE_WINOGRAD_UP") && atoi(getenv("SE_WINOGRAD_UP")) == 0);
+  if (use_wino && use_winoup && d.up && L.d_u && L.d_ub && !src1 && C0 == 96 && d.cin == 96 &&
+      (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0) {
+    WinoParams wp;
+    memset(&wp, 0, sizeof wp);
+    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
+    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = 1; wp.th = Hin / 2; wp.tw = Win / 2;
+    wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+    wp.xcd = xcd_remap_enabled();
+    udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
+    udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
+    udiv_magic_host(1u, &wp.div_d_m, &wp.div_d_l);
+    set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9,
+                    4.0 * ((double)B * Hin * Win * 96 + (double)B * Ho * Wo * 48), d.name);
+    HIPCHK(c, launch_winoup(wp, c->st));
     return 0;
   }
   GConvParams p;

@@ -13,7 +13,7 @@ namespace se {
 // Optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline
 // figures.  Off by default; when off the launch wrappers add nothing.
 // ---------------------------------------------------------------------------------------------
-enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL_WINO_N192, PL_WINO_N96, PL_SMALL_CONV, PL_PACK, PL_COLREDUCE,
+enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL_WINO_N192, PL_WINO_N96, PL_WINO_UP96, PL_SMALL_CONV, PL_PACK, PL_COLREDUCE,
                  PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
 const char* prof_label_name(int l);
 struct Profiler {
@@ -98,6 +98,9 @@ struct WinoParams {
 hipError_t launch_wino(const WinoParams& p, hipStream_t st);
 // 48 -> 96 form (se_wino48.hip): src / dst NHWC 48 channels, upk [24 iterations][96 MIXED rows][32], bias [96] MIXED order
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
+// gen_deconv 96 -> 96 (48 gated), F(2x2,2x2) on the 4 sub-pixel classes (se_wino_up.hip): src NHWC 96 at (h, w), dst NHWC
+// 48 at (2h, 2w), upk [4 classes][27 iterations][96 MIXED rows][32], bias [96] MIXED order; h, w even; th = h/2, tw = w/2
+hipError_t launch_winoup(const WinoParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 conv 12 -> {1,3} raw output + fused tanh/sigmoid/composite (final layer of each decoder)

@@ -13,7 +13,7 @@ static thread_local const char* g_next_name = nullptr;
 void set_profiler(Profiler* p) { g_prof = p; }
 void set_launch_cost(double flops, double bytes, const char* name) { g_next_flops = flops; g_next_bytes = bytes; g_next_name = name; }
 const char* prof_label_name(int l) {
-  static const char* n[PL_COUNT] = {"gconv_n192", "gconv_n96", "gconv_n48", "gconv_n24", "wino_n192", "wino_n96", "small_conv", "pack",
+  static const char* n[PL_COUNT] = {"gconv_n192", "gconv_n96", "gconv_n48", "gconv_n24", "wino_n192", "wino_n96", "wino_up96", "small_conv", "pack",
                                     "colreduce", "att_prep", "att_score", "att_softmax", "att_pv", "layout"};
   return (l >= 0 && l < PL_COUNT) ? n[l] : "?";
 }

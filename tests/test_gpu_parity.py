@@ -138,6 +138,26 @@ def test_op_winograd48_path_vs_oracle(eng, case):
     assert _md(y, ref) < TOL_OP
 
 
+WINOUP = [(8, 8, "elu"), (16, 24, "elu"), (64, 64, "elu"), (10, 14, "relu"), (34, 30, "elu"), (2, 2, "elu")]
+
+
+@pytest.mark.parametrize("case", WINOUP, ids=["%dx%d-%s" % c for c in WINOUP])
+def test_op_winograd_upsample_path_vs_oracle(eng, case):
+    """gen_deconv 96 -> 96 (nearest x2 + 3x3): F(2x2,2x2) Winograd on the four sub-pixel classes (se_wino_up.hip);
+    even source sizes take it, ragged tile counts and the image borders (zero padding on the upsampled grid) included."""
+    from oracle import sketchedit_oracle as O
+    H, W, act = case
+    a = 1.5 / np.sqrt(96 * 9)
+    w = synth.uniform(19, "winoup.w%s" % (case,), (96, 96, 3, 3), -a, a)
+    b = synth.uniform(19, "winoup.b%s" % (case,), (96,), -0.3, 0.3)
+    x = synth.uniform(19, "winoup.x%s" % (case,), (3, 96, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, upsample=True, act=act)
+    xu = torch.from_numpy(x).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)      # utils.py:47
+    ref = O.gated_conv(xu, torch.from_numpy(w), torch.from_numpy(b), 1, 1, act)
+    assert tuple(y.shape) == (3, 48, 2 * H, 2 * W)
+    assert _md(y, ref) < TOL_OP
+
+
 def test_op_attention_vs_oracle(eng):
     from oracle import sketchedit_oracle as O
     x = synth.uniform(5, "att96.x", (2, 96, 12, 16), -1, 1)

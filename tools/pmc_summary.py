@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96",
+LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96", "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96",
           "gconv_kernel<3": "gconv_n48", "gconv_kernel<2": "gconv_n24"}
 
 
