@@ -220,15 +220,17 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   f32x4 r[4];
   set_pos(0, 0);
 #pragma unroll
-  for (int i0 = 0; i0 < 2; ++i0) {     // chunks 0, 1 of position 0
-    load_x(i0, r);
-    write_x(i0, r);
-  }
-#pragma unroll
-  for (int i0 = 0; i0 < 3; ++i0) {
+  for (int i0 = 0; i0 < 3; ++i0) {     // the W DMA first: its latency overlaps the granule round trip
     dma_w(i0, i0, 0);
     dma_w(i0, i0, 1);
     dma_w(i0, i0, 2);
+  }
+  {
+    f32x4 r1[4];                       // chunks 0, 1 of position 0: both loads in flight before the first transform
+    load_x(0, r);
+    load_x(1, r1);
+    write_x(0, r);
+    write_x(1, r1);
   }
   dma_wait_all();
   __syncthreads();

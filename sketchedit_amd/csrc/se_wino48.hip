@@ -190,13 +190,16 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   set_pos(0, 0);
   set_pos(1, 1);
 #pragma unroll
-  for (int i0 = 0; i0 < 2; ++i0) {
+  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); }     // W DMA first: overlaps the granule round trip
+  {
+    f32x4 r1[2][4];                    // iterations 0 and 1: both sets of loads in flight before the first transform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { load_x1(i0, r, 0, i); load_x1(i0, r, 1, i); }
-    write_x(i0, i0, r);
+    for (int i = 0; i < 4; ++i) { load_x1(0, r, 0, i); load_x1(0, r, 1, i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { load_x1(1, r1, 0, i); load_x1(1, r1, 1, i); }
+    write_x(0, 0, r);
+    write_x(1, 1, r1);
   }
-#pragma unroll
-  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); }
   set_pos(0, 2);                       // even position of pair 1 (iteration 3 on)
   dma_wait_all();
   __syncthreads();
