@@ -221,3 +221,34 @@ def test_batching_server_groups_by_size_and_preserves_results():
     srv.close()
     with pytest.raises(RuntimeError, match="closed"):
         srv.submit(*reqs[0])
+
+
+def test_check_checkpoint_tool(tmp_path):
+    """tools/check_checkpoint.py: a DataParallel-prefixed pair validates (104 / 48 tensors), a wrong shape, a missing
+    and an unexpected key are reported (util/util.py:214-225 contract, without a GPU)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_check_ckpt", os.path.join(root, "tools", "check_checkpoint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = tmp_path / "celeb"
+    os.makedirs(d)
+    G = {"module." + k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()}
+    M = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()}
+    torch.save(G, d / "latest_net_G.pth")
+    torch.save(M, d / "latest_net_M.pth")
+    assert mod.main([str(d), "--npz", str(tmp_path / "w")]) == 0
+    z = np.load(tmp_path / "w_G.npz")
+    assert len(z.files) == 104 and sum(z[k].size for k in z.files) == 5366430
+    assert len(np.load(tmp_path / "w_M.npz").files) == 48
+    clean, problems = mod.check_state_dict("G", G)
+    assert not problems and len(clean) == 104
+    bad = dict(M)
+    bad["conv3.weight"] = bad["conv3.weight"][:, :, :2]
+    del bad["conv5.bias"]
+    bad["extra.weight"] = torch.zeros(1)
+    _, problems = mod.check_state_dict("M", bad)
+    text = "\n".join(problems)
+    assert "size mismatch for conv3.weight" in text and "missing key conv5.bias" in text and "unexpected key extra.weight" in text
+    torch.save(bad, d / "latest_net_M.pth")
+    assert mod.main([str(d)]) == 1
