@@ -107,24 +107,28 @@ struct NoHook { DEVFN void operator()(int) const {} };
 template <int NT, int PT, typename Hook = NoHook>
 DEVFN void mfma_chunk(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const char* __restrict__ Xt, int off0,
                       int off1, Hook hook = Hook()) {
+  // all B (pixel) fragments of the chunk up front, the A (channel) fragments one tile ahead -- also across the two
+  // k-halves, so no LDS latency sits between the halves
+  f32x4 xb[2][PT];
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xb[half][pt] = *(const f32x4*)(Xt + pt * 2048 + (half ? off1 : off0));
+  f32x4 wn = *(const f32x4*)(Wt + off0);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const int off = half ? off1 : off0;
-    f32x4 xb[PT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) xb[pt] = *(const f32x4*)(Xt + pt * 2048 + off);
-    f32x4 wn = *(const f32x4*)(Wt + off);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 wa = wn;
-      if (nt + 1 < NT) wn = *(const f32x4*)(Wt + (nt + 1) * 2048 + off);   // fragment prefetch, one tile ahead
+      if (nt + 1 < NT) wn = *(const f32x4*)(Wt + (nt + 1) * 2048 + (half ? off1 : off0));
+      else if (half == 0) wn = *(const f32x4*)(Wt + off1);
       // k-step outer, pixel tile inner: consecutive MFMAs never share an accumulator (a dependent
       // v_mfma_f32_16x16x4_f32 issues after 40 cycles instead of 32 when the wave has the pipe to itself)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
-          acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], xb[pt][r], acc[nt][pt], 0, 0, 0);
+          acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r], xb[half][pt][r], acc[nt][pt], 0, 0, 0);
       }
       hook(half * NT + nt);
     }
