@@ -36,7 +36,19 @@ enum {
   SE_FLAG_POOL_MAX = 2,        /* --pool_type max (unset: avg) */
   SE_FLAG_NO_MASK_CC = 4,      /* --no_mask_cc */
   SE_FLAG_NO_MASK_COARSE = 8,  /* --no_mask_coarse */
-  SE_FLAG_JOINT_TRAIN_INP = 16 /* --joint_train_inp */
+  SE_FLAG_JOINT_TRAIN_INP = 16, /* --joint_train_inp */
+  /* execution options (no reference counterpart; the results agree with the default mode to fp32 rounding, and an
+   * image's result is bit-identical across batch positions / ranks WITHIN one mode):
+   * LOW_LATENCY: for one or two images per call (test_celeb.sh:2 --batchSize 1, demo.py:59): small-grid kernel shapes that
+   * put every CU to work and the independent branches of netG on two streams (the ctx's side stream is ordered after /
+   * before the caller's stream through events -- no host synchronisation).
+   * GRAPH (se_inference only): capture the forward for these exact arguments into a hipGraph on its second use and
+   * replay it afterwards; the caller keeps every pointer argument (inputs, outputs, workspace) stable. */
+  SE_FLAG_LOW_LATENCY = 32,
+  SE_FLAG_GRAPH = 64,
+  /* PACKED_OUT (se_inference only): composed_out points at ONE (B,4,H,W) buffer -- planes 0-2 the composite, plane 3
+   * the soft mask (mask_out is ignored and may be NULL): the unit a batch-sharded caller all-gathers. */
+  SE_FLAG_PACKED_OUT = 128
 };
 
 /* replaces networks.create_network's .cuda() (models/networks/__init__.py:30-38) */
@@ -95,6 +107,13 @@ int se_profile_report(se_ctx* ctx, char* buf, size_t cap);
  * Supported: gated Cout%8==0 (any Cin, k in {3,5}); raw only for k=3, Cin=12, Cout in {1,3}. */
 int se_gated_conv2d(se_ctx* ctx, void* stream, const float* x, const float* w_host, const float* b_host, float* y,
                     int B, int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample);
+/* The same with the options the forwards use: a second source x1 of the virtual channel concat in front of conv11 /
+ * allconv11 (editline_g.py:166-167,211) -- a tensor (B,Cin1,H,W), or with x1_is_vector a spatially constant per-image
+ * vector (B,Cin1), still zero padded at the borders; w is (Cout, Cin+Cin1, k, k) -- and exec_flags = SE_FLAG_LOW_LATENCY
+ * to run the layer in its small-grid launch shape.  x1 may be NULL. */
+int se_gated_conv2d_ex(se_ctx* ctx, void* stream, const float* x, const float* x1, int x1_is_vector, const float* w_host,
+                       const float* b_host, float* y, int B, int Cin, int Cin1, int H, int W, int Cout, int k, int stride,
+                       int rate, int act, int upsample, int exec_flags);
 /* cam_1 + cam_2 (models/networks/splitcam.py:57-108,147-174 as configured at editline_g.py:35-42,
  * 203-207): x (B,96,h,w), mask_full (B,1,4h,4w) -> out (B,96,h,w); similar_out (B,L,hs,ws) may be NULL. */
 int se_attention(se_ctx* ctx, void* stream, const float* x, const float* mask_full, float* out, float* similar_out,

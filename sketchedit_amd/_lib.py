@@ -19,11 +19,14 @@ SOURCES = ["se_gconv.hip", "se_wino.hip", "se_wino48.hip", "se_wino_up.hip", "se
 
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
+FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT = 32, 64, 128          # execution options (include/sketchedit_hip.h)
+# calls of at most this many pixels (two 256x256 images) run in the low-latency mode unless the caller says otherwise
+LOW_LATENCY_MAX_PIXELS = 2 * 256 * 256
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
            "se_workspace_bytes", "se_netM_forward", "se_netG_forward", "se_inference", "se_gated_conv2d",
-           "se_attention", "se_quantize_u8", "se_profile_enable", "se_profile_report"]
+           "se_gated_conv2d_ex", "se_attention", "se_quantize_u8", "se_profile_enable", "se_profile_report"]
 
 
 class SketchEditHipError(RuntimeError):
@@ -82,6 +85,8 @@ def load_library():
         lib.se_inference.restype = ci
         lib.se_gated_conv2d.argtypes = [vp, vp, c_f, c_f, c_f, c_f] + [ci] * 10
         lib.se_gated_conv2d.restype = ci
+        lib.se_gated_conv2d_ex.argtypes = [vp, vp, c_f, c_f, ci, c_f, c_f, c_f] + [ci] * 12
+        lib.se_gated_conv2d_ex.restype = ci
         lib.se_attention.argtypes = [vp, vp, c_f, c_f, c_f, c_f, ci, ci, ci]
         lib.se_attention.restype = ci
         lib.se_quantize_u8.argtypes = [vp, vp, c_f, c_f, vp, vp, ci, ci, ci]
@@ -153,6 +158,8 @@ class Engine:
         self.h = h
         self._ws = None
         self._ws_lock = threading.Lock()
+        self._ws_stream = None
+        self._static = {}          # graph mode: per-shape input copies and output buffers (stable pointers)
 
     def close(self):
         if getattr(self, "h", None):
@@ -189,8 +196,18 @@ class Engine:
         if need == 0:
             self._err("se_workspace_bytes")
         with self._ws_lock:
+            cur = torch.cuda.current_stream(self.device)
             if self._ws is None or self._ws.numel() < need:
+                if self._ws is not None:
+                    # earlier forwards may still be using the old block on their stream: keep the caching allocator
+                    # from handing it out before they finish
+                    self._ws.record_stream(self._ws_stream)
                 self._ws = torch.empty(need, dtype=torch.uint8, device="cuda:%d" % self.device)
+                self._static.clear()       # captured graphs are keyed by the workspace pointer
+            elif self._ws_stream is not None and self._ws_stream != cur:
+                # one workspace = one stream: forwards on another stream must not overlap the previous ones
+                cur.wait_stream(self._ws_stream)
+            self._ws_stream = cur
             return self._ws
 
     def _stream(self):
@@ -222,26 +239,63 @@ class Engine:
             self._err("se_netG_forward")
         return coarse, fine
 
-    def inference(self, image, sketch, flags, visualize=False, out=None):
-        """-> dict(composed, mask[, hard, maskim, coarse, fine]).  `out` may hold preallocated composed/mask."""
+    def exec_flags(self, B, H, W, low_latency=None, graph=False):
+        """Execution-option bits for a call: low-latency mode is chosen by size unless forced (True / False)."""
+        if low_latency is None:
+            low_latency = B * H * W <= LOW_LATENCY_MAX_PIXELS
+        return (FLAG_LOW_LATENCY if low_latency else 0) | (FLAG_GRAPH if graph else 0)
+
+    def inference(self, image, sketch, flags, visualize=False, out=None, low_latency=None, graph=False):
+        """-> dict(composed, mask[, hard, maskim, coarse, fine]).  `out` may hold preallocated composed/mask.
+
+        low_latency: None = by size (small calls), True / False = forced.  graph=True replays the forward from a
+        captured hipGraph: that needs stable pointers, so the inputs are copied into buffers this Engine keeps per
+        shape and the returned tensors ARE the per-shape output buffers -- consume them before the next call of the
+        same shape."""
         import torch
         _check_dev(image, sketch)
         B, _, H, W = image.shape
         ws = self.workspace(B, H, W)
         dev = image.device
-        composed = out["composed"] if out else torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        mask = out["mask"] if out else torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        r = dict(composed=composed, mask=mask)
-        hard = maskim = coarse = fine = None
-        if visualize:
-            hard = torch.empty_like(mask)
-            maskim, coarse, fine = (torch.empty_like(composed) for _ in range(3))
-            r.update(hard=hard, maskim=maskim, coarse=coarse, fine=fine)
-        if self.lib.se_inference(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(composed), _ptr(mask),
-                                 _ptr(hard), _ptr(maskim), _ptr(coarse), _ptr(fine), _ptr(ws), ws.numel(), B, H, W,
-                                 flags):
+        flags = (flags & 31) | self.exec_flags(B, H, W, low_latency, graph)
+
+        def new_outputs(have=None):
+            mk = lambda c: torch.empty((B, c, H, W), dtype=torch.float32, device=dev)     # noqa: E731
+            o = dict(composed=have["composed"], mask=have["mask"]) if have else dict(composed=mk(3), mask=mk(1))
+            if visualize:
+                o.update(hard=mk(1), maskim=mk(3), coarse=mk(3), fine=mk(3))
+            return o
+
+        if graph:
+            key = (B, H, W, bool(visualize))
+            st = self._static.get(key)
+            if st is None:
+                st = self._static[key] = {"image": torch.empty_like(image), "sketch": torch.empty_like(sketch),
+                                          "outs": new_outputs()}
+            st["image"].copy_(image)
+            st["sketch"].copy_(sketch)
+            image, sketch = st["image"], st["sketch"]
+            r = dict(st["outs"])
+        else:
+            r = new_outputs(out)
+        if self.lib.se_inference(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(r["composed"]), _ptr(r["mask"]),
+                                 _ptr(r.get("hard")), _ptr(r.get("maskim")), _ptr(r.get("coarse")), _ptr(r.get("fine")),
+                                 _ptr(ws), ws.numel(), B, H, W, flags):
             self._err("se_inference")
         return r
+
+    def inference_packed(self, image, sketch, flags, out, low_latency=None):
+        """Inference into ONE (B,4,H,W) buffer `out`: planes 0-2 composed, plane 3 the soft mask -- the unit the
+        batch-sharded path all-gathers (sketchedit_amd/shard.py)."""
+        _check_dev(image, sketch, out)
+        B, _, H, W = image.shape
+        assert tuple(out.shape) == (B, 4, H, W)
+        ws = self.workspace(B, H, W)
+        flags = (flags & 31) | self.exec_flags(B, H, W, low_latency, False) | FLAG_PACKED_OUT
+        if self.lib.se_inference(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(out), None, None, None, None,
+                                 None, _ptr(ws), ws.numel(), B, H, W, flags):
+            self._err("se_inference")
+        return out
 
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, on):
@@ -255,13 +309,17 @@ class Engine:
         return json.loads(buf.value.decode())
 
     # ---- per-op entry points (unit tests) --------------------------------------------------------
-    def gated_conv2d(self, x, w, b, stride=1, rate=1, act="elu", upsample=False):
+    def gated_conv2d(self, x, w, b, stride=1, rate=1, act="elu", upsample=False, x1=None, low_latency=False):
+        """gen_conv / gen_deconv on x, or on the virtual concat cat([x, x1]) where x1 is a (B,C1,H,W) tensor or a
+        (B,C1) per-image vector (broadcast over the image, zero padded at the borders)."""
         import torch
-        _check_dev(x)
+        _check_dev(x, x1)
         w = np.ascontiguousarray(w, np.float32)
         b = np.ascontiguousarray(b, np.float32)
         B, Cin, H, W = x.shape
-        Cout, _, k, _ = w.shape
+        Cout, CinT, k, _ = w.shape
+        Cin1 = 0 if x1 is None else x1.shape[1]
+        assert CinT == Cin + Cin1
         pad = int(rate * (k - 1) / 2)
         if upsample:
             Ho, Wo = 2 * H, 2 * W
@@ -271,10 +329,11 @@ class Engine:
         raw = act is None or Cout == 3
         y = torch.empty((B, Cout if raw else Cout // 2, Ho, Wo), dtype=torch.float32, device=x.device)
         acode = {"elu": 0, "relu": 1, None: 2}[act]
-        if self.lib.se_gated_conv2d(self.h, self._stream(), _ptr(x), w.ctypes.data_as(ctypes.c_void_p),
-                                    b.ctypes.data_as(ctypes.c_void_p), _ptr(y), B, Cin, H, W, Cout, k, stride, rate,
-                                    acode, int(upsample)):
-            self._err("se_gated_conv2d")
+        if self.lib.se_gated_conv2d_ex(self.h, self._stream(), _ptr(x), _ptr(x1), int(x1 is not None and x1.dim() == 2),
+                                       w.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), _ptr(y),
+                                       B, Cin, Cin1, H, W, Cout, k, stride, rate, acode, int(upsample),
+                                       FLAG_LOW_LATENCY if low_latency else 0):
+            self._err("se_gated_conv2d_ex")
         return y
 
     def quantize_u8(self, composed, mask):

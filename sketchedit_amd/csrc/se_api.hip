@@ -81,11 +81,13 @@ struct Arena {
   size_t cap = 0, peak = 0;
   bool dry = false;
   char* base = nullptr;
-  void reset(char* b, size_t c, bool d) {
-    base = d ? (char*)4096 : b;   // dry runs only measure: any non-null fake base
-    cap = d ? (size_t)1 << 62 : c; dry = d; peak = 0;
+  void reset(char* b, size_t c, bool d, int which = 0) {
+    // dry runs only measure: any non-null fake base (the two arenas of a plan get disjoint fake ranges)
+    base = d ? (char*)(which ? ((size_t)1 << 62) + 4096 : 4096) : b;
+    cap = d ? (size_t)1 << 61 : c; dry = d; peak = 0;
     blks.clear(); blks.push_back({0, cap, false});
   }
+  bool owns(const void* p) const { return (size_t)p >= (size_t)base && (size_t)p < (size_t)base + cap; }
   float* alloc(size_t nfloats) {
     size_t need = (nfloats * 4 + 255) & ~(size_t)255;
     for (size_t i = 0; i < blks.size(); ++i) {
@@ -126,10 +128,23 @@ struct se_ctx {
   std::map<std::string, Layer> G, M;
   Layer wconv1_j4;          // G.wconv1 packed for a 4-channel input: with --joint_train_inp its guide channel is zero
   float* zeros = nullptr;   // zero page for out-of-bounds granules
-  Arena arena;
-  hipStream_t st = nullptr;
+  Arena arena;              // workspace arena of the main branch
+  Arena arena2;             // low-latency mode: arena of the concurrent side branch (disjoint region of the workspace)
+  hipStream_t st = nullptr; // stream the next launch goes to
+  hipStream_t st_main = nullptr;
+  hipStream_t st_side = nullptr;        // side-branch stream (created with the ctx, non-blocking)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dry = false;
+  bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
   Profiler prof;
+  struct Peaks { size_t main, side; };
+  std::map<std::vector<long long>, Peaks> peaks;      // dry-run arena peaks per (B, H, W, flags, outputs wanted)
+  struct GraphEntry {
+    std::vector<long long> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+  };
+  std::vector<GraphEntry> graphs;                     // SE_FLAG_GRAPH: captured forwards, keyed by every argument
 };
 
 namespace {
@@ -425,10 +440,22 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   if (c->dry) return 0;
   if (!L.packed) return fail(c, "layer %s: weights not loaded", d.name);
   if ((C0 + C1) != L.CGp * 4) return fail(c, "layer %s: source channels %d+%d != packed %d", d.name, C0, C1, L.CGp * 4);
-  static const bool use_wino = !(getenv("SE_WINOGRAD") && atoi(getenv("SE_WINOGRAD")) == 0);
+  // Low-latency mode (SE_FLAG_LOW_LATENCY, one or two images): the Winograd kernels' 64/128-tile workgroups would
+  // occupy 16-32 of the 256 CUs, so every gated conv takes the direct kernel in its small-grid shape instead
+  // (launch_gconv: 64-pixel tiles, rows split over blockIdx.y).  2.25x more multiply-adds on ~10x more CUs.
+  static const bool use_wino_env = !(getenv("SE_WINOGRAD") && atoi(getenv("SE_WINOGRAD")) == 0);
+  const bool use_wino = use_wino_env && !c->low_latency;
   const bool wino_src_ok = (!src1 && C0 == 96 && d.cin == 96) || (src1 && C0 == 96 && C1 == 96 && d.cin == 192);
   // the kernel addresses a source through 32-bit byte offsets (96 floats per pixel)
   const bool wino_addr_ok = (long long)B * Hin * Win * 384 < (1ll << 31);
+  if (use_wino && !d.up && L.d_u && wino_src_ok && !wino_addr_ok) {
+    static bool said = false;
+    if (!said) {
+      said = true;
+      fprintf(stderr, "sketchedit_hip: layer %s: %d x %dx%d x 96 floats exceed the Winograd kernel's 32-bit byte offsets; "
+                      "using the direct kernel (about 2x slower) -- split the batch\n", d.name, B, Hin, Win);
+    }
+  }
   if (use_wino && !d.up && L.d_u && wino_src_ok && wino_addr_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
@@ -441,7 +468,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
     udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
-    set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name);
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 16.0 / 36.0);      // F(2x2,3x3): 16 of 36 products
     HIPCHK(c, launch_wino(wp, c->st));
     return 0;
   }
@@ -457,7 +485,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
     udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
     udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
-    set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9, 4.0 * 2.0 * (double)B * Hin * Win * 48, d.name);
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 48, d.name, alg * 16.0 / 36.0);
     HIPCHK(c, launch_wino48(wp, c->st));
     return 0;
   }
@@ -473,8 +502,9 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
     udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
     udiv_magic_host(1u, &wp.div_d_m, &wp.div_d_l);
-    set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9,
-                    4.0 * ((double)B * Hin * Win * 96 + (double)B * Ho * Wo * 48), d.name);
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * 96 + (double)B * Ho * Wo * 48), d.name,
+                    alg * 9.0 / 36.0);                       // F(2x2,2x2) on the sub-pixel classes: 9 of 36 products
     HIPCHK(c, launch_winoup(wp, c->st));
     return 0;
   }
@@ -501,9 +531,15 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   p.Hlim = Hin; p.Wlim = Win;
   p.src1_vec = src1_vec; p.nch = L.nch; p.G = L.G; p.act = d.act; p.total_pix = B * p.Ho * p.Wo;
   p.xcd = xcd_remap_enabled();
+  p.np_full = L.NP; p.nf_full = L.NP / 32; p.small_grid = c->low_latency ? 1 : 0;
   // algorithmic cost as the reference defines the layer (3x3 on the upsampled grid for gen_deconv)
-  set_launch_cost(2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k,
-                  4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name);
+  {
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k;
+    // executed: the packed K (channels padded to granules, taps x channels padded to 32) and row (NP) sizes the MFMAs
+    // really run over; the sub-pixel form of gen_deconv runs 4 classes x 4 taps instead of 9 taps on the upsampled grid
+    const double exec = 2.0 * (double)B * p.Ho * p.Wo * (d.up ? 4.0 : 1.0) * L.NP * (L.nch * 32.0);
+    set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name, exec);
+  }
   HIPCHK(c, launch_gconv(L.cfg, p, c->st));
   return 0;
 }
@@ -518,14 +554,50 @@ struct Plan {
   std::map<std::string, Layer>& net;
   int B;
   int rc = 0;
-  Plan(se_ctx* c_, std::map<std::string, Layer>& n, int B_) : c(c_), net(n), B(B_) {}
+  Arena* ar;                // arena of the branch being planned
+  Plan(se_ctx* c_, std::map<std::string, Layer>& n, int B_) : c(c_), net(n), B(B_), ar(&c_->arena) {}
+  float* alloc_raw(size_t nfloats) {
+    float* p = ar->alloc(nfloats);
+    if (!p && !rc) rc = fail(c, "workspace too small (need more than %zu bytes)", ar->cap);
+    return p;
+  }
   Act alloc(int H, int W, int C) {
     Act a; a.H = H; a.W = W; a.C = C;
-    a.p = c->arena.alloc((size_t)B * H * W * C);
-    if (!a.p && !rc) rc = fail(c, "workspace too small (need more than %zu bytes)", c->arena.cap);
+    a.p = alloc_raw((size_t)B * H * W * C);
     return a;
   }
-  void free(Act& a) { c->arena.release(a.p); a.p = nullptr; }
+  void release(const float* p) {          // to whichever arena the block came from
+    if (!p) return;
+    if (c->arena2.owns(p)) c->arena2.release(p); else c->arena.release(p);
+  }
+  void free(Act& a) { release(a.p); a.p = nullptr; }
+  // ---- concurrent branches (low-latency mode).  side_begin() .. side_end() plans a branch on the side stream and in the
+  // side arena; it starts after everything enqueued on the main stream so far (fork event) and join() makes the main
+  // stream wait for it.  A buffer shared by both branches must be released only after join().  Outside low-latency mode
+  // the calls do nothing: the branch is planned in line, on the main stream and arena.
+  bool forked() const { return c->low_latency && c->st_side; }
+  int side_begin() {
+    if (!forked()) return 0;
+    ar = &c->arena2;
+    if (c->dry) return 0;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->st_main));
+    HIPCHK(c, hipStreamWaitEvent(c->st_side, c->ev_fork, 0));
+    c->st = c->st_side;
+    return 0;
+  }
+  int side_end() {
+    if (!forked()) return 0;
+    ar = &c->arena;
+    if (c->dry) return 0;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->st_side));
+    c->st = c->st_main;
+    return 0;
+  }
+  int join() {
+    if (!forked() || c->dry) return 0;
+    HIPCHK(c, hipStreamWaitEvent(c->st_main, c->ev_join, 0));
+    return 0;
+  }
   // gated conv layer: consumes (and releases, if `rel`) `in`
   Act conv(const char* name, Act& in, bool rel = true, const float* src1 = nullptr, int C1 = 0, int vec = 0) {
     if (rc) return Act();
@@ -575,7 +647,7 @@ Act decoder(Plan& P, const std::string& p, Act& in, const float* src1 = nullptr,
 }
 
 int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* hard, const float* img,
-          const float* mask, float* xnow, float* composed, int no_mask_coarse) {
+          const float* mask, float* xnow, float* composed, int no_mask_coarse, long packed_bs = 0) {
   if (P.rc) return P.rc;
   se_ctx* c = P.c;
   if (!c->dry) {
@@ -586,6 +658,10 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
     sp.x = in.p; sp.w = L.d_w; sp.b = L.d_b; sp.B = P.B; sp.H = in.H; sp.W = in.W; sp.cout = L.def.cout;
     sp.mode = mode; sp.out_nchw = out_nchw; sp.hard = hard; sp.img = img; sp.mask = mask; sp.xnow = xnow;
     sp.composed = composed; sp.no_mask_coarse = no_mask_coarse;
+    if (packed_bs) {      // SE_FLAG_PACKED_OUT: soft mask and composite live in one (B,4,H,W) buffer
+      if (mode == 0) sp.out_bs = packed_bs;
+      if (mode == 3) { sp.mask_bs = packed_bs; sp.comp_bs = packed_bs; }
+    }
     set_launch_cost(2.0 * (double)P.B * in.H * in.W * L.def.cout * 108.0,
                     4.0 * (double)P.B * in.H * in.W * (12 + L.def.cout), L.def.name);
     hipError_t e = launch_small_conv(sp, c->st);
@@ -597,7 +673,7 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
 
 // MDGenerator.forward, editline2_g.py:59-94
 int plan_netM(se_ctx* c, const float* image, const float* sketch, float* mask_out, float* hard_out, float* maskim_out,
-              int B, int H, int W) {
+              int B, int H, int W, long packed_bs = 0) {
   Plan P(c, c->M, B);
   Act in = P.alloc(H, W, 4);
   if (P.rc) return P.rc;
@@ -610,52 +686,51 @@ int plan_netM(se_ctx* c, const float* image, const float* sketch, float* mask_ou
     small(P, "conv17", d, 1, maskim_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   }
   Act d = decoder(P, "conv_mask_", x10);
-  small(P, "conv_mask_17", d, 0, mask_out, hard_out, nullptr, nullptr, nullptr, nullptr, 0);
+  small(P, "conv_mask_17", d, 0, mask_out, hard_out, nullptr, nullptr, nullptr, nullptr, 0, packed_bs);
   return P.rc;
 }
 
 int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, float* similar_nchw);
 
-// DeepFillC2Generator.forward, editline_g.py:119-221
+// DeepFillC2Generator.forward, editline_g.py:119-221.  The two encoders of stage 1 and the two branches of stage 2 are
+// independent until their concat: in low-latency mode the second one of each pair runs on the side stream.
 int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
               float* coarse_out, float* fine_out, const float* soft_mask, float* composed_out, int B, int H, int W,
-              int flags) {
+              int flags, long packed_bs = 0) {
   Plan P(c, c->G, B);
   const int joint = (flags & SE_FLAG_JOINT_TRAIN_INP) ? 1 : 0;
   // joint_train_inp: the style input is packed without its (zero) guide channel and wconv1 runs as a 4-channel conv
-  Act cin = P.alloc(H, W, 8), sin = P.alloc(H, W, joint ? 4 : 8);
+  Act cin = P.alloc(H, W, 8);
+  P.ar = P.forked() ? &c->arena2 : &c->arena;       // the style branch's input lives in the style branch's arena
+  Act sin = P.alloc(H, W, joint ? 4 : 8);
+  P.ar = &c->arena;
   if (P.rc) return P.rc;
   if (!c->dry)
     HIPCHK(c, launch_pack_g(x, x2, mask, mask2, guide, cin.p, sin.p, B, H, W, (flags & SE_FLAG_NO_MASK_CC) ? 1 : 0,
                             joint, c->st));
-  Act xc = encoder(P, "conv", cin, nullptr);        // :138-147
-  Act xs = encoder(P, "wconv", sin, nullptr, joint ? &c->wconv1_j4 : nullptr);       // :149-158
-  // global pool of the style branch -> (B,96) vector, consumed as second (spatially constant) source
+  // ---- style branch :149-163 -> (B,96) pooled vector, consumed by conv11 as a second (spatially constant) source
+  if (P.side_begin()) return 1;
+  Act xs = encoder(P, "wconv", sin, nullptr, joint ? &c->wconv1_j4 : nullptr);
   Act part = P.alloc(1, COLREDUCE_SPLITS, 96), vec = P.alloc(1, 1, 96);
   if (P.rc) return P.rc;
   if (!c->dry)
     HIPCHK(c, launch_colreduce(xs.p, part.p, vec.p, B, xs.H * xs.W, 96, (flags & SE_FLAG_POOL_MAX) ? 0 : 1, c->st));
   P.free(xs);
   P.free(part);
+  if (P.side_end()) return 1;
+  // ---- coarse branch :138-147
+  Act xc = encoder(P, "conv", cin, nullptr);
+  if (P.rc) return P.rc;
+  if (P.join()) return 1;
   Act d = decoder(P, "conv", xc, vec.p, 96, 1);     // :167-175 (cat is virtual)
   P.free(vec);
   Act xnow = P.alloc(H, W, 4);
   if (P.rc) return P.rc;
   small(P, "conv17", d, 2, coarse_out, nullptr, x, mask, xnow.p, nullptr, (flags & SE_FLAG_NO_MASK_COARSE) ? 1 : 0);
   if (P.rc) return P.rc;
-  // hallucination branch :184-194
-  Act hcur = P.conv("xconv1", xnow, false);
-  hcur = P.conv("xconv2_downsample", hcur);
-  hcur = P.conv("xconv3", hcur);
-  hcur = P.conv("xconv4_downsample", hcur);
-  hcur = P.conv("xconv5", hcur);
-  hcur = P.conv("xconv6", hcur);
-  hcur = P.conv("xconv7_atrous", hcur);
-  hcur = P.conv("xconv8_atrous", hcur);
-  hcur = P.conv("xconv9_atrous", hcur);
-  Act hallu = P.conv("xconv10_atrous", hcur);
-  // patch-match branch :197-209
-  Act pm = P.conv("pmconv1", xnow);
+  // ---- patch-match branch :197-209 (side)
+  if (P.side_begin()) return 1;
+  Act pm = P.conv("pmconv1", xnow, false);
   pm = P.conv("pmconv2_downsample", pm);
   pm = P.conv("pmconv3", pm);
   pm = P.conv("pmconv4_downsample", pm);
@@ -671,34 +746,66 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   pm = P.conv("pmconv9", pm);
   pm = P.conv("pmconv10", pm);
   if (P.rc) return P.rc;
+  if (P.side_end()) return 1;
+  // ---- hallucination branch :184-194
+  Act hcur = P.conv("xconv1", xnow, false);
+  hcur = P.conv("xconv2_downsample", hcur);
+  hcur = P.conv("xconv3", hcur);
+  hcur = P.conv("xconv4_downsample", hcur);
+  hcur = P.conv("xconv5", hcur);
+  hcur = P.conv("xconv6", hcur);
+  hcur = P.conv("xconv7_atrous", hcur);
+  hcur = P.conv("xconv8_atrous", hcur);
+  hcur = P.conv("xconv9_atrous", hcur);
+  Act hallu = P.conv("xconv10_atrous", hcur);
+  if (P.rc) return P.rc;
+  if (P.join()) return 1;
+  P.free(xnow);                                         // read by both branches: released after the join
   Act d2 = decoder(P, "allconv", hallu, pm.p, 96, 0);   // cat([x_hallu, pm]) :211 is virtual
   P.free(pm);
-  small(P, "allconv17", d2, 3, fine_out, nullptr, x, soft_mask, nullptr, soft_mask ? composed_out : nullptr, 0);
+  small(P, "allconv17", d2, 3, fine_out, nullptr, x, soft_mask, nullptr, soft_mask ? composed_out : nullptr, 0, packed_bs);
   return P.rc;
 }
 
 int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, float* similar_nchw) {
   const int h = x.H, w = x.W, B = P.B;
   const int hs = (h - 4) / 2 + 1, ws = (w - 4) / 2 + 1, L = hs * ws, Lp = (L + 31) & ~31;
+  const int hc = h / 2, wc = w / 2, R = hc * wc, Rp = (R + 31) & ~31;
+  const bool v2 = attention_v2_enabled();
+  if (v2 && (double)R * Rp * 4.0 >= 2147483648.0) return P.rc = fail(c, "attention: %dx%d feature map too large", h, w);
   Act part = P.alloc(1, COLREDUCE_SPLITS, 96), rn = P.alloc(1, 1, 96), xn = P.alloc(h, w, 96);
-  Act valid, S;
-  valid.p = c->arena.alloc((size_t)B * Lp);
-  S.p = c->arena.alloc((size_t)B * L * Lp);
-  if (!part.p || !rn.p || !xn.p || !valid.p || !S.p) return P.rc = fail(c, "workspace too small (attention)");
+  float *valid = nullptr, *S = nullptr, *S2 = nullptr, *xT = nullptr;
+  if (v2) {
+    valid = P.ar->alloc((size_t)B * Rp);
+    xT = P.ar->alloc((size_t)B * 4 * 96 * Rp);
+    S = P.ar->alloc((size_t)B * R * Rp);       // E, then P~
+    S2 = P.ar->alloc((size_t)B * R * Rp);      // P
+  } else {
+    valid = P.ar->alloc((size_t)B * Lp);
+    S = P.ar->alloc((size_t)B * L * Lp);
+  }
+  if (!part.p || !rn.p || !xn.p || !valid || !S || (v2 && (!S2 || !xT))) return P.rc = fail(c, "workspace too small (attention)");
   if (!c->dry) {
     HIPCHK(c, launch_colreduce(x.p, part.p, rn.p, B, h * w, 96, 2, c->st));
     AttParams a;
     memset(&a, 0, sizeof a);
-    a.x = x.p; a.rn = rn.p; a.xn = xn.p; a.hard = mask_full; a.valid = valid.p; a.S = S.p; a.out = out.p;
+    a.x = x.p; a.rn = rn.p; a.xn = xn.p; a.hard = mask_full; a.out = out.p;
     a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.L = L; a.Lp = Lp;
     a.scale = 10.f; a.th = 0.1f;                        // editline_g.py:35-38
-    HIPCHK(c, launch_attention(a, c->st));
-    if (similar_nchw) {
-      // (B, Lk, hs, ws) <- S[b][i][j]: "channel" j, pixel i
-      HIPCHK(c, launch_nhwc_to_nchw(S.p, similar_nchw, B, L, Lp, hs, ws, c->st));
+    if (v2) {
+      a.hc = hc; a.wc = wc; a.R = R; a.Rp = Rp;
+      a.validR = valid; a.xT = xT; a.E = S; a.P = S2; a.similar = similar_nchw;
+      HIPCHK(c, launch_attention(a, c->st));
+    } else {
+      a.valid = valid; a.S = S;
+      HIPCHK(c, launch_attention(a, c->st));
+      if (similar_nchw) {
+        // (B, Lk, hs, ws) <- S[b][i][j]: "channel" j, pixel i
+        HIPCHK(c, launch_nhwc_to_nchw(S, similar_nchw, B, L, Lp, hs, ws, c->st));
+      }
     }
   }
-  c->arena.release(S.p); c->arena.release(valid.p);
+  P.release(S2); P.release(S); P.release(xT); P.release(valid);
   P.free(xn); P.free(rn); P.free(part);
   return 0;
 }
@@ -706,6 +813,59 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
 int check_dims(se_ctx* c, int B, int H, int W) {
   if (B < 1 || H < 16 || W < 16 || (H % 8) || (W % 8)) return fail(c, "bad shape B=%d H=%d W=%d (H, W must be multiples of 8, >= 16)", B, H, W);
   return 0;
+}
+
+// Arena peaks of a forward, from a dry run of the very plan that will be launched (nothing is enqueued): main-branch
+// arena and, in low-latency mode, the side-branch arena.  which: 1 netM, 2 netG, 3 netM then netG (se_inference).
+se_ctx::Peaks plan_peaks(se_ctx* c, int which, int B, int H, int W, int flags, bool want_maskim) {
+  const std::vector<long long> key = {which, B, H, W, flags & (SE_FLAG_USE_CAM | SE_FLAG_JOINT_TRAIN_INP | SE_FLAG_LOW_LATENCY),
+                                      want_maskim ? 1 : 0, attention_v2_enabled() ? 1 : 0};
+  auto it = c->peaks.find(key);
+  if (it != c->peaks.end()) return it->second;
+  const bool dry0 = c->dry, ll0 = c->low_latency;
+  c->dry = true;
+  c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
+  float dummy;      // non-null marker for optional outputs
+  se_ctx::Peaks pk{0, 0};
+  if (which & 1) {
+    c->arena.reset(nullptr, 0, true, 0); c->arena2.reset(nullptr, 0, true, 1);
+    plan_netM(c, nullptr, nullptr, nullptr, nullptr, want_maskim ? &dummy : nullptr, B, H, W);
+    pk.main = c->arena.peak; pk.side = c->arena2.peak;
+  }
+  if (which & 2) {
+    c->arena.reset(nullptr, 0, true, 0); c->arena2.reset(nullptr, 0, true, 1);
+    plan_netG(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, flags);
+    if (c->arena.peak > pk.main) pk.main = c->arena.peak;
+    if (c->arena2.peak > pk.side) pk.side = c->arena2.peak;
+  }
+  c->dry = dry0; c->low_latency = ll0;
+  c->peaks[key] = pk;
+  return pk;
+}
+
+// carve the caller's workspace into the arenas of this call; `tail` bytes at the end stay reserved
+int carve(se_ctx* c, const se_ctx::Peaks& pk, void* ws, size_t ws_bytes, size_t tail) {
+  if (ws_bytes < pk.main + pk.side + tail)
+    return fail(c, "workspace too small: %zu bytes, this call needs %zu", ws_bytes, pk.main + pk.side + tail);
+  // the main arena gets whatever the side arena does not need
+  c->arena.reset((char*)ws, ws_bytes - tail - pk.side, false);
+  c->arena2.reset((char*)ws + (ws_bytes - tail - pk.side), pk.side, false);
+  return 0;
+}
+
+void begin_call(se_ctx* c, void* stream, int flags) {
+  c->st = c->st_main = (hipStream_t)stream;
+  c->dry = false;
+  c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
+  set_profiler(&c->prof);
+}
+
+void drop_graphs(se_ctx* c) {
+  for (auto& g : c->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  c->graphs.clear();
 }
 
 }  // namespace
@@ -728,6 +888,13 @@ int se_create(int device_id, se_ctx** out) {
     delete c;
     return fail(nullptr, "device init failed");
   }
+  // side-branch stream + fork/join events of the low-latency mode (concurrent branches of netG)
+  if (hipStreamCreateWithFlags(&c->st_side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    se_destroy(c);
+    return fail(nullptr, "stream / event creation failed");
+  }
   for (int i = 0; i < NG; ++i) c->G[G_LAYERS[i].name].def = G_LAYERS[i];
   for (int i = 0; i < NM; ++i) c->M[M_LAYERS[i].name].def = M_LAYERS[i];
   *out = c;
@@ -748,15 +915,27 @@ void se_destroy(se_ctx* c) {
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
   if (c->zeros) (void)hipFree(c->zeros);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
+  drop_graphs(c);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->st_side) (void)hipStreamDestroy(c->st_side);
   delete c;
 }
 
-const char* se_last_error(se_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+// the message of the last failed call on this ctx, copied under the ctx lock into a per-thread buffer (threaded callers)
+const char* se_last_error(se_ctx* c) {
+  if (!c) return g_create_err.c_str();
+  thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(c->mu);
+  copy = c->err;
+  return copy.c_str();
+}
 
 int se_load_weights(se_ctx* c, int net_id, const char* name, const float* host, const int* shape, int ndim) {
   if (!c || !name || !host || !shape) return 1;
   std::lock_guard<std::mutex> lk(c->mu);
   (void)hipSetDevice(c->device);
+  drop_graphs(c);                       // captured forwards hold the old weight images
   std::string key(name);
   if (key.rfind("module.", 0) == 0) key = key.substr(7);          // util/util.py:221-222
   const size_t dot = key.rfind('.');
@@ -793,32 +972,32 @@ int se_weights_ready(se_ctx* c) {
 }
 
 size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
-  if (!c || check_dims(c, B, H, W)) return 0;
+  if (!c) return 0;
   std::lock_guard<std::mutex> lk(c->mu);
-  c->dry = true;
+  if (check_dims(c, B, H, W)) return 0;
+  // every flag combination that changes the allocation sequence (a first-fit arena does not peak monotonically):
+  // attention on/off, 4- or 8-channel style input, in-line or concurrent branches
   size_t peak = 0;
-  float dummy;   // non-null marker for optional outputs
-  c->arena.reset(nullptr, 0, true);
-  plan_netM(c, nullptr, nullptr, nullptr, nullptr, &dummy, B, H, W);
-  peak = c->arena.peak;
-  c->arena.reset(nullptr, 0, true);
-  plan_netG(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W,
-            SE_FLAG_USE_CAM | SE_FLAG_POOL_MAX);      // without joint_train_inp: the larger (8-channel) style input
-  if (c->arena.peak > peak) peak = c->arena.peak;
-  c->dry = false;
-  return peak + ((size_t)B * H * W * 4 + 256);   // + hard-mask plane used by se_inference
+  for (int cam = 0; cam < 2; ++cam)
+    for (int joint = 0; joint < 2; ++joint)
+      for (int ll = 0; ll < 2; ++ll) {
+        const int flags = (cam ? SE_FLAG_USE_CAM : 0) | (joint ? SE_FLAG_JOINT_TRAIN_INP : 0) | (ll ? SE_FLAG_LOW_LATENCY : 0) |
+                          SE_FLAG_POOL_MAX;
+        const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, true);
+        if (pk.main + pk.side > peak) peak = pk.main + pk.side;
+      }
+  return peak + (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask plane used by se_inference
 }
 
 int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
                     float* maskim_out, void* ws, size_t ws_bytes, int B, int H, int W) {
   if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
-  std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  c->st = (hipStream_t)stream; c->dry = false;
-  set_profiler(&c->prof);
-  c->arena.reset((char*)ws, ws_bytes, false);
+  if (carve(c, plan_peaks(c, 1, B, H, W, 0, maskim_out != nullptr), ws, ws_bytes, 0)) return 1;
+  begin_call(c, stream, 0);
   return plan_netM(c, image, sketch, mask_out, nullptr, maskim_out, B, H, W);
 }
 
@@ -826,46 +1005,91 @@ int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, co
                     const float* guide, float* coarse_out, float* fine_out, void* ws, size_t ws_bytes, int B, int H,
                     int W, int flags) {
   if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 1;
   if (!x || !x2 || !mask || !mask2 || !guide || !fine_out || !ws) return fail(c, "null pointer argument");
-  std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  c->st = (hipStream_t)stream; c->dry = false;
-  set_profiler(&c->prof);
-  c->arena.reset((char*)ws, ws_bytes, false);
+  if (carve(c, plan_peaks(c, 2, B, H, W, flags, false), ws, ws_bytes, 0)) return 1;
+  begin_call(c, stream, flags);
   return plan_netG(c, x, x2, mask, mask2, guide, coarse_out, fine_out, nullptr, nullptr, B, H, W, flags);
 }
+
+namespace {
+// netM -> threshold -> netG -> composite, enqueued on `stream` (and, in low-latency mode, the ctx's side stream)
+int enqueue_inference(se_ctx* c, void* stream, const float* image, const float* sketch, float* composed_out, float* mask_out,
+                      float* hard_out, float* maskim_out, float* coarse_out, float* fine_out, void* ws, size_t ws_bytes,
+                      int B, int H, int W, int flags) {
+  // the hard mask lives at the end of the workspace for the whole call
+  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
+  const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, maskim_out != nullptr);
+  if (carve(c, pk, ws, ws_bytes, plane)) return 1;
+  float* hard = hard_out ? hard_out : (float*)((char*)ws + ws_bytes - plane);
+  // SE_FLAG_PACKED_OUT: composed_out is one (B,4,H,W) buffer, planes 0-2 the composite, plane 3 the soft mask
+  const long packed_bs = (flags & SE_FLAG_PACKED_OUT) ? 4l * H * W : 0;
+  if (packed_bs) mask_out = composed_out + 3l * H * W;
+  begin_call(c, stream, flags);
+  int rc = plan_netM(c, image, sketch, mask_out, hard, maskim_out, B, H, W, packed_bs);     // editline2_model.py:339,346-347
+  if (rc) return rc;
+  if (carve(c, pk, ws, ws_bytes, plane)) return 1;
+  // netG(inputs, inputs, mask_inpaint, mask_inpaint, line)  :366-368 ; composite with the soft mask :132
+  return plan_netG(c, image, image, hard, hard, sketch, coarse_out, fine_out, mask_out, composed_out, B, H, W, flags,
+                   packed_bs);
+}
+}  // namespace
 
 int se_inference(se_ctx* c, void* stream, const float* image, const float* sketch, float* composed_out,
                  float* mask_out, float* hard_out, float* maskim_out, float* coarse_out, float* fine_out, void* ws,
                  size_t ws_bytes, int B, int H, int W, int flags) {
   if (!c) return 1;
-  if (check_dims(c, B, H, W)) return 1;
-  if (!image || !sketch || !composed_out || !mask_out || !ws) return fail(c, "null pointer argument");
   std::lock_guard<std::mutex> lk(c->mu);
+  if (check_dims(c, B, H, W)) return 1;
+  if (!image || !sketch || !composed_out || (!mask_out && !(flags & SE_FLAG_PACKED_OUT)) || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
-  c->st = (hipStream_t)stream; c->dry = false;
-  set_profiler(&c->prof);
-  // the hard mask lives at the end of the workspace for the whole call
-  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
-  if (ws_bytes < plane) return fail(c, "workspace too small");
-  float* hard = hard_out ? hard_out : (float*)((char*)ws + ws_bytes - plane);
-  const size_t arena_bytes = ws_bytes - plane;
-  c->arena.reset((char*)ws, arena_bytes, false);
-  int rc = plan_netM(c, image, sketch, mask_out, hard, maskim_out, B, H, W);     // editline2_model.py:339,346-347
-  if (rc) return rc;
-  c->arena.reset((char*)ws, arena_bytes, false);
-  // netG(inputs, inputs, mask_inpaint, mask_inpaint, line)  :366-368 ; composite with the soft mask :132
-  return plan_netG(c, image, image, hard, hard, sketch, coarse_out, fine_out, mask_out, composed_out, B, H, W, flags);
+  if (!(flags & SE_FLAG_GRAPH) || c->prof.on)
+    return enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out, fine_out, ws,
+                             ws_bytes, B, H, W, flags);
+  // SE_FLAG_GRAPH: the forward for these exact arguments (every pointer is baked into the kernel nodes) is captured
+  // into a hipGraph the second time it is seen and replayed from then on: one launch instead of ~85, and the two
+  // branches of the low-latency mode become parallel graph nodes.  The first call runs eagerly (it also sets the
+  // per-device kernel attributes, which must not happen under capture).
+  const std::vector<long long> key = {(long long)(size_t)image, (long long)(size_t)sketch, (long long)(size_t)composed_out,
+                                      (long long)(size_t)mask_out, (long long)(size_t)hard_out, (long long)(size_t)maskim_out,
+                                      (long long)(size_t)coarse_out, (long long)(size_t)fine_out, (long long)(size_t)ws,
+                                      (long long)ws_bytes, B, H, W, flags};
+  se_ctx::GraphEntry* ge = nullptr;
+  for (auto& g : c->graphs)
+    if (g.key == key) { ge = &g; break; }
+  if (!ge) {
+    if (c->graphs.size() >= 16) drop_graphs(c);
+    c->graphs.emplace_back();
+    c->graphs.back().key = key;
+    return enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out, fine_out, ws,
+                             ws_bytes, B, H, W, flags);
+  }
+  if (!ge->exec) {
+    HIPCHK(c, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out,
+                                     fine_out, ws, ws_bytes, B, H, W, flags);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(c, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) { (void)hipGraphDestroy(graph); return fail(c, "hipGraphInstantiate failed: %s", hipGetErrorString(e2)); }
+    ge->graph = graph; ge->exec = exec;
+  }
+  HIPCHK(c, hipGraphLaunch(ge->exec, (hipStream_t)stream));
+  return 0;
 }
 
 // test.py:25-27 on the device
 int se_quantize_u8(se_ctx* c, void* stream, const float* composed, const float* mask, unsigned char* rgb_out,
                    unsigned char* mask_u8_out, int B, int H, int W) {
   if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 1;
   if ((rgb_out && !composed) || (mask_u8_out && !mask)) return fail(c, "null pointer argument");
-  std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   set_profiler(&c->prof);
   HIPCHK(c, launch_quantize_u8(composed, mask, rgb_out, mask_u8_out, B, H, W, (hipStream_t)stream));
@@ -892,19 +1116,19 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  double ms[PL_COUNT] = {0}, fl[PL_COUNT] = {0}, by[PL_COUNT] = {0};
+  double ms[PL_COUNT] = {0}, fl[PL_COUNT] = {0}, by[PL_COUNT] = {0}, ex[PL_COUNT] = {0};
   long n[PL_COUNT] = {0};
   for (auto& r : c->prof.recs) {
     float t = 0.f;
-    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.label] += t; fl[r.label] += r.flops; by[r.label] += r.bytes; n[r.label]++; }
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.label] += t; fl[r.label] += r.flops; ex[r.label] += r.exec_flops; by[r.label] += r.bytes; n[r.label]++; }
   }
   std::string s = "{\"kernels\": [";
   bool first = true;
   for (int l = 0; l < PL_COUNT; ++l) {
     if (!n[l]) continue;
-    char t[256];
-    snprintf(t, sizeof t, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-             first ? "" : ", ", prof_label_name(l), n[l], ms[l], fl[l], by[l]);
+    char t[384];
+    snprintf(t, sizeof t, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"flops_executed\": %.6e, \"bytes\": %.6e}",
+             first ? "" : ", ", prof_label_name(l), n[l], ms[l], fl[l], ex[l], by[l]);
     s += t;
     first = false;
   }
@@ -912,6 +1136,7 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
   // per (kernel, layer name) in first-seen order
   std::vector<std::string> keys;
   std::map<std::string, std::pair<double, double>> agg;   // ms, flops
+  std::map<std::string, double> aggx;                       // executed flops
   std::map<std::string, long> cnt;
   for (auto& r : c->prof.recs) {
     if (!r.name) continue;
@@ -919,13 +1144,13 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     std::string k = std::string(prof_label_name(r.label)) + ":" + r.name;
     if (!cnt.count(k)) keys.push_back(k);
-    agg[k].first += t; agg[k].second += r.flops; cnt[k]++;
+    agg[k].first += t; agg[k].second += r.flops; aggx[k] += r.exec_flops; cnt[k]++;
   }
   first = true;
   for (auto& k : keys) {
-    char t[256];
-    snprintf(t, sizeof t, "%s{\"layer\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e}", first ? "" : ", ",
-             k.c_str(), cnt[k], agg[k].first, agg[k].second);
+    char t[384];
+    snprintf(t, sizeof t, "%s{\"layer\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"flops_executed\": %.6e}",
+             first ? "" : ", ", k.c_str(), cnt[k], agg[k].first, agg[k].second, aggx[k]);
     s += t;
     first = false;
   }
@@ -936,26 +1161,36 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
 }
 
 // ---- unit-test entry points (allocate scratch internally; synchronise the stream before freeing) ----
-int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host, const float* b_host, float* y, int B,
-                    int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample) {
+int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1, int x1_is_vector, const float* w_host,
+                       const float* b_host, float* y, int B, int Cin, int Cin1, int H, int W, int Cout, int k, int stride,
+                       int rate, int act, int upsample, int exec_flags) {
   if (!c || !x || !w_host || !b_host || !y) return 1;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  c->st = (hipStream_t)stream; c->dry = false;
-  set_profiler(&c->prof);
+  begin_call(c, stream, exec_flags & SE_FLAG_LOW_LATENCY);
+  if (!x1) Cin1 = 0;
+  if (x1 && ((Cin % 4) || (Cin1 % 4))) return fail(c, "two-source conv: channel counts must be multiples of 4");
   Layer L;
   static const char* nm = "test";
-  L.def = LayerDef{nm, Cin, Cout, k, stride, rate, act, upsample};
-  L.w.assign(w_host, w_host + (size_t)Cout * Cin * k * k);
+  const int CinT = Cin + Cin1;
+  L.def = LayerDef{nm, CinT, Cout, k, stride, rate, act, upsample};
+  L.w.assign(w_host, w_host + (size_t)Cout * CinT * k * k);
   L.b.assign(b_host, b_host + Cout);
   const int Cp = (Cin + 3) & ~3;
-  float *xin = nullptr, *yout = nullptr;
+  float *xin = nullptr, *x1in = nullptr, *yout = nullptr;
   int rc = 0;
   HIPCHK(c, hipMalloc(&xin, (size_t)B * H * W * Cp * 4));
   rc = launch_nchw_to_nhwc(x, xin, B, Cin, Cp, H, W, c->st) != hipSuccess;
+  if (!rc && x1) {
+    // second source of the virtual concat (editline_g.py:166-167,211): a tensor (B,Cin1,H,W) or a per-image vector (B,Cin1)
+    const size_t n1 = x1_is_vector ? (size_t)B * Cin1 : (size_t)B * H * W * Cin1;
+    HIPCHK(c, hipMalloc(&x1in, n1 * 4));
+    if (x1_is_vector) rc = hipMemcpyAsync(x1in, x1, n1 * 4, hipMemcpyDeviceToDevice, c->st) != hipSuccess;
+    else rc = launch_nchw_to_nhwc(x1, x1in, B, Cin1, Cin1, H, W, c->st) != hipSuccess;
+  }
   const bool raw = (act == ACT_NONE) || Cout == 3;    // utils.py:27
   if (!rc && raw) {
-    if (k != 3 || Cin != 12 || (Cout != 1 && Cout != 3) || stride != 1 || rate != 1 || upsample) rc = fail(c, "raw conv: only 3x3 12->{1,3}");
+    if (k != 3 || CinT != 12 || x1 || (Cout != 1 && Cout != 3) || stride != 1 || rate != 1 || upsample) rc = fail(c, "raw conv: only 3x3 12->{1,3}");
     if (!rc) rc = pack_small(c, L);
     if (!rc) {
       SmallConvParams sp;
@@ -966,17 +1201,18 @@ int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host
     }
   } else if (!rc) {
     if (Cout % 8) rc = fail(c, "gated conv needs Cout %% 8 == 0");
-    if (!rc) rc = pack_layer(c, L, identity_map(Cin));
+    if (!rc) rc = pack_layer(c, L, identity_map(CinT));
     if (!rc) {
       int Ho, Wo;
       c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
       HIPCHK(c, hipMalloc(&yout, (size_t)B * Ho * Wo * (Cout / 2) * 4));
-      rc = run_gconv(c, L, xin, Cp, nullptr, 0, 0, yout, B, H, W, nullptr, nullptr);
+      rc = run_gconv(c, L, xin, Cp, x1in, Cin1, x1_is_vector, yout, B, H, W, nullptr, nullptr);
       if (!rc) rc = launch_nhwc_to_nchw(yout, y, B, Cout / 2, Cout / 2, Ho, Wo, c->st) != hipSuccess;
     }
   }
   (void)hipStreamSynchronize(c->st);
   if (xin) (void)hipFree(xin);
+  if (x1in) (void)hipFree(x1in);
   if (yout) (void)hipFree(yout);
   if (L.d_w) (void)hipFree(L.d_w);
   if (L.d_b) (void)hipFree(L.d_b);
@@ -985,19 +1221,25 @@ int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host
   return rc;
 }
 
+int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host, const float* b_host, float* y, int B,
+                    int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample) {
+  return se_gated_conv2d_ex(c, stream, x, nullptr, 0, w_host, b_host, y, B, Cin, 0, H, W, Cout, k, stride, rate, act,
+                            upsample, 0);
+}
+
 int se_attention(se_ctx* c, void* stream, const float* x, const float* mask_full, float* out, float* similar_out, int B,
                  int h, int w) {
   if (!c || !x || !mask_full || !out) return 1;
   if (h < 4 || w < 4 || (h % 2) || (w % 2)) return fail(c, "attention: h, w must be even and >= 4");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  c->st = (hipStream_t)stream; c->dry = false;
-  set_profiler(&c->prof);
-  const int hs = (h - 4) / 2 + 1, ws_ = (w - 4) / 2 + 1, L = hs * ws_, Lp = (L + 31) & ~31;
-  const size_t bytes = ((size_t)B * h * w * 96 * 3 + (size_t)B * L * Lp + (size_t)B * Lp + 64 * 96 * B) * 4 + (1 << 16);
+  begin_call(c, stream, 0);
+  const int R = (h / 2) * (w / 2), Rp = (R + 31) & ~31;
+  const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (1 + 4 * 96) + 64 * 96 * B) * 4 + (1 << 16);
   char* ws = nullptr;
   HIPCHK(c, hipMalloc(&ws, bytes));
   c->arena.reset(ws, bytes, false);
+  c->arena2.reset(nullptr, 0, false);
   Plan P(c, c->G, B);
   Act xin = P.alloc(h, w, 96), o = P.alloc(h, w, 96);
   int rc = P.rc;

@@ -13,6 +13,8 @@
 // K = 4 (covering patch) x L (keys) -- deterministic, no atomics.
 #include "se_device.h"
 
+#include <cstdlib>
+
 namespace se {
 
 __global__ void att_prep_kernel(const AttParams p) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void att_pv_kernel(const AttParams p) {
   }
 }
 
-hipError_t launch_attention(const AttParams& p, hipStream_t st) {
+static hipError_t launch_attention_v1(const AttParams& p, hipStream_t st) {
   {
     const long n = (long)p.B * p.h * p.w * 24;
     ProfScope ps_(st, PL_ATT_PREP);
@@ -284,13 +286,10 @@ hipError_t launch_attention(const AttParams& p, hipStream_t st) {
   {
     constexpr int NT = 4, PT = 4;
     constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
-    static bool set = false;
-    if (!set) {
-      hipError_t e = hipFuncSetAttribute((const void*)att_score_kernel<NT, PT>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) return e;
-      set = true;
-    }
+    {
+    hipError_t e = ensure_max_lds((const void*)att_score_kernel<NT, PT>, LDS);
+    if (e != hipSuccess) return e;
+  }
     dim3 grid((p.L + PT * 64 - 1) / (PT * 64), (p.L + NT * 16 - 1) / (NT * 16), p.B);
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 0.0);
     ProfScope ps_(st, PL_ATT_SCORE);
@@ -304,13 +303,10 @@ hipError_t launch_attention(const AttParams& p, hipStream_t st) {
   {
     constexpr int PT = 4;
     constexpr int LDS = 2 * PT * 64 * 128 + 2 * 32 * 384;
-    static bool set = false;
-    if (!set) {
-      hipError_t e = hipFuncSetAttribute((const void*)att_pv_kernel<PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         LDS);
-      if (e != hipSuccess) return e;
-      set = true;
-    }
+    {
+    hipError_t e = ensure_max_lds((const void*)att_pv_kernel<PT>, LDS);
+    if (e != hipSuccess) return e;
+  }
     const int cpix = (p.h >> 1) * (p.w >> 1);
     dim3 grid((cpix + PT * 64 - 1) / (PT * 64), 4, p.B);
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 0.0);
@@ -318,6 +314,358 @@ hipError_t launch_attention(const AttParams& p, hipStream_t st) {
     hipLaunchKernelGGL((att_pv_kernel<PT>), grid, dim3(256), LDS, st, p);
   }
   return hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// Space-to-depth form ("v2", the default).  The 4x4 patches at stride 2 overlap: tap (ky,kx) of patch i is pixel
+// 2i + (ky,kx), so a score is a sum of per-pixel dot products that neighbouring (query, key) pairs share,
+//   S[i][j] = sum_{d in {0,1}^2} E[i+d][j+d],   E[r][s] = sum_{cls, c} x[2r+cls][c] * xn[2s+cls][c]
+// with r, s on the class grid hc x wc = h/2 x w/2 (i, j on its (hc-1) x (wc-1) sub-grid) and cls the 4 pixel parities:
+// E is ONE GEMM of the space-to-depth tensors, K = 4*96 = 384 instead of 16*96 = 1536 per score.  The same
+// identity on the output side: an output pixel of class cls at grid position r sums P over the <= 4 patches covering it,
+//   out[2r+cls] = sum_s P~[r][s] * x[2s+cls],      P~[r][s] = sum_{d} P[r-d][s-d],
+// one GEMM with K = R = hc*wc instead of 4*L.  Together 3.75x fewer multiply-adds than the patch form above
+// (2*R^2*384*2 vs 2*L^2*1536*2 per image), and both GEMMs run the shared 32-k chunk core with b128 fragments
+// (the values are staged transposed, [class][channel][key], so the A operand is k-contiguous).
+// Kernels: prep (xn, key validity, transposed values) -> E GEMM -> row softmax (forms S from E on the fly; one wave per
+// query) -> P~ box sum (one wave per row) -> P~.V GEMM per class (blockIdx.y; the four class workgroups of a pixel tile
+// land on the same XCD -- linear block id % 8 -- and share the P~ tile through its L2).  Deterministic, no atomics.
+// Summation order differs from the reference's conv (fp32 rounding only): measured <= 2e-6 on `similar`.
+// =====================================================================================================================
+
+__global__ void att2_prep_kernel(const AttParams p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nx = (long)p.B * p.h * p.w * 24;    // granules
+  if (idx < nx) {
+    const int cg = idx % 24;
+    const long pix = idx / 24;
+    const int b = pix / (p.h * p.w);
+    const f32x4 v = *(const f32x4*)(p.x + idx * 4);
+    const f32x4 r = *(const f32x4*)(p.rn + b * 96 + cg * 4);
+    *(f32x4*)(p.xn + idx * 4) = v * r;                        // splitcam.py:40
+  }
+  if (idx < (long)p.B * p.Rp) {
+    const int b = idx / p.Rp, s = idx - (long)b * p.Rp;
+    float val = -1.f;                                          // not a key position
+    const int sy = s / p.wc, sx = s - sy * p.wc;
+    if (s < p.R && sy < p.hs && sx < p.ws) {
+      const int H = p.h * 4, W = p.w * 4;
+      // the 4x4 patch of the avg-pooled map covers a 16x16 full-resolution window; for a {0,1} mask the
+      // sum is an integer <= 256, so the mean is exact and the > 0.1 test is order independent (splitcam.py:49-53)
+      float hole = 0.f;
+      for (int yy = 0; yy < 16; ++yy)
+        for (int xx = 0; xx < 16; ++xx) hole += p.hard[((long)b * H + sy * 8 + yy) * W + sx * 8 + xx];
+      const float mm = 1.f - hole * (1.f / 256.f);
+      val = mm > p.th ? 1.f : 0.f;
+    }
+    p.validR[idx] = val;
+  }
+}
+
+// xT[b][cls][c][s] = x[b][2sy+py][2sx+px][c] (raw values, splitcam.py:138-143), zero for s >= R.  Block = 32 keys of one class.
+__global__ __launch_bounds__(256) void att2_transpose_kernel(const AttParams p) {
+  __shared__ float t[32][97];
+  const int s0 = blockIdx.x * 32, cls = blockIdx.y, b = blockIdx.z, py = cls >> 1, px = cls & 1;
+  for (int e = threadIdx.x; e < 32 * 96; e += 256) {
+    const int sl = e / 96, c = e - sl * 96, s = s0 + sl;
+    float v = 0.f;
+    if (s < p.R) {
+      const int sy = s / p.wc, sx = s - sy * p.wc;
+      v = p.x[((size_t)(b * p.h + 2 * sy + py) * p.w + 2 * sx + px) * 96 + c];
+    }
+    t[sl][c] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 96 * 32; e += 256) {
+    const int c = e >> 5, sl = e & 31;
+    p.xT[(((size_t)b * 4 + cls) * 96 + c) * p.Rp + s0 + sl] = t[sl][c];
+  }
+}
+
+// E[b][r][s] = <2x2x96 block of x at class-grid position r, 2x2x96 block of xn at s>; rows of the A tile = keys s,
+// MFMA columns = queries r; written query-major so that the softmax axis is contiguous.
+template <int NT, int PT>
+__global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
+  constexpr int PIX = PT * 64, NP = NT * 16;
+  constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
+  constexpr int NX = PT * 2, NW = (NT * 2 + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  char* Wb = smem + 2 * XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
+  // byte offset of the 2x2 block origin of a row inside THIS image, or an out-of-range offset (hardware zero fill)
+  auto origin = [&](int i) -> unsigned {
+    if (i >= p.R) return 0x80000000u;
+    const int ry = i / p.wc, rx = i - ry * p.wc;
+    return (unsigned)(((2 * ry) * p.w + 2 * rx) * 384);
+  };
+  const se_i32x4 rs_q = make_rsrc(p.x + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
+  const se_i32x4 rs_k = make_rsrc(p.xn + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
+  unsigned qo[NX], ko[NW];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) qo[i] = origin(q0 + (i * 4 + w) * 8 + (lane >> 3));
+#pragma unroll
+  for (int j = 0; j < NW; ++j) ko[j] = (j * 4 + w) < NT * 2 ? origin(k0 + (j * 4 + w) * 8 + (lane >> 3)) : 0x80000000u;
+
+  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
+
+  auto stage = [&](int ch, int buf) {
+    const int gi = ch * 8 + s_log;                 // granule of the 4 pixels x 24 channel groups
+    const int tap = (gi * 2731) >> 16, cg = gi - tap * 24;      // gi / 24 for gi < 4096
+    const unsigned doff = (unsigned)((__mul24(tap >> 1, p.w) + (tap & 1)) * 384 + cg * 16);
+    const unsigned xdst = lds_x + buf * XBYTES, wdst = lds_w + buf * WBYTES;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) bufdma16(qo[i] + doff, rs_q, xdst + (i * 4 + w) * 1024);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int rbk = j * 4 + w;
+      if (rbk < NT * 2) bufdma16(ko[j] + doff, rs_k, wdst + rbk * 1024);
+    }
+  };
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NCH = 12;   // 4 pixels * 96 ch / 32
+  stage(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < NCH) stage(ch + 1, buf ^ 1);
+    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    dma_wait_all();
+    __syncthreads();
+  }
+  const int q = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int j = k0 + nt * 16 + q * 4;
+    if (j >= p.Rp) continue;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int i = q0 + (w * PT + pt) * 16 + (lane & 15);
+      if (i < p.R) *(f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j) = acc[nt][pt];
+    }
+  }
+}
+
+// One wave per query i: S[j] = scale * valid[j] * sum_d E[i+d][j+d] (splitcam.py:69,90,104), softmax over the keys
+// (:105); written in class-grid indexing, zero at the grid positions that are not keys and in the pad columns.
+__global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= (long)p.B * p.L) return;
+  const int b = qi / p.L, i = qi - (long)b * p.L;
+  const int iy = i / p.ws, ix = i - iy * p.ws;
+  const int r0 = iy * p.wc + ix;
+  const float* E0 = p.E + ((size_t)b * p.R + r0) * p.Rp;      // (iy, ix)
+  const float* E1 = E0 + p.Rp;                                // (iy, ix+1)
+  const float* E2 = E0 + (size_t)p.wc * p.Rp;                 // (iy+1, ix)
+  const float* E3 = E2 + p.Rp;                                // (iy+1, ix+1)
+  const float* vr = p.validR + (size_t)b * p.Rp;
+  float* P = p.P + ((size_t)b * p.R + r0) * p.Rp;
+  const int o2 = p.wc, o3 = p.wc + 1;
+  float m = -INFINITY;
+  for (int s = lane; s < p.R; s += 64) {
+    const float v = vr[s];
+    if (v >= 0.f) {      // a key: sy < hc-1 and sx < wc-1, so s + wc + 1 < R
+      const float sc = (E0[s] + E1[s + 1] + E2[s + o2] + E3[s + o3]) * v * p.scale;
+      P[s] = sc;
+      m = fmaxf(m, sc);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float sum = 0.f;
+  for (int s = lane; s < p.R; s += 64) {
+    if (vr[s] >= 0.f) {
+      const float e = expf(P[s] - m);      // each lane re-reads only what it wrote itself
+      P[s] = e;
+      sum += e;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  for (int s = lane; s < p.Rp; s += 64) {
+    float o = 0.f;
+    if (s < p.R && vr[s] >= 0.f) o = P[s] * inv;
+    P[s] = o;
+  }
+}
+
+// One wave per class-grid row r: P~[r][s] = sum over the <= 4 patches (query r-d, key s-d) that pair pixel r with pixel s.
+// P is zero at non-key columns, so only s - d < 0 needs a test on the key side.  Overwrites E.
+__global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= (long)p.B * p.R) return;
+  const int b = qi / p.R, r = qi - (long)b * p.R;
+  const int ry = r / p.wc, rx = r - ry * p.wc;
+  const float* Pb = p.P + (size_t)b * p.R * p.Rp;
+  float* out = p.E + ((size_t)b * p.R + r) * p.Rp;
+  const float* src[4];
+  int off[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int dy = d >> 1, dx = d & 1, qy = ry - dy, qx = rx - dx;
+    const bool ok = qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;       // wave-uniform
+    src[d] = ok ? Pb + (size_t)(qy * p.wc + qx) * p.Rp : nullptr;
+    off[d] = dy * p.wc + dx;
+  }
+  for (int s = lane; s < p.Rp; s += 64) {
+    float a = 0.f;
+    if (s < p.R) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        if (src[d] && s >= off[d]) a += src[d][s - off[d]];
+    }
+    out[s] = a;
+  }
+}
+
+// out[b, 2r + cls, c] = sum_s P~[r][s] * xT[cls][c][s]: A tile = 96 channel rows x 32 keys, MFMA columns = class-grid pixels
+template <int PT>
+__global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
+  constexpr int NT = 6, PIX = PT * 64, NP = 96;
+  constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
+  constexpr int NX = PT * 2, NW = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;                        // P~ tiles [PIX][32 keys]
+  char* Wb = smem + 2 * XBYTES;           // V^T tiles [96 ch][32 keys]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, cls = blockIdx.y, py = cls >> 1, px = cls & 1;
+  const int t0 = blockIdx.x * PIX;
+  const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
+  const se_i32x4 rs_P = make_rsrc(p.E + (size_t)b * p.R * p.Rp, (unsigned)p.R * p.Rp * 4u);
+  const se_i32x4 rs_V = make_rsrc(p.xT + ((size_t)b * 4 + cls) * 96 * p.Rp, 96u * p.Rp * 4u);
+  unsigned xo[NX], wo[NW];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int r = t0 + (i * 4 + w) * 8 + (lane >> 3);
+    xo[i] = r < p.R ? (unsigned)(r * p.Rp + s_log * 4) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int j = 0; j < NW; ++j) wo[j] = (unsigned)(((j * 4 + w) * 8 + (lane >> 3)) * p.Rp + s_log * 4) * 4u;
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
+  const int nch = p.Rp >> 5;
+
+  auto stage = [&](int ch, int buf) {
+    const unsigned delta = (unsigned)ch * 128u;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) bufdma16(xo[i] + delta, rs_P, lds_x + buf * XBYTES + (i * 4 + w) * 1024);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) bufdma16(wo[j] + delta, rs_V, lds_w + buf * WBYTES + (j * 4 + w) * 1024);
+  };
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) stage(ch + 1, buf ^ 1);
+    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    dma_wait_all();
+    __syncthreads();
+  }
+  const int q = lane >> 4;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int i = t0 + (w * PT + pt) * 16 + (lane & 15);
+    if (i >= p.R) continue;
+    const int yy = i / p.wc, xx = i - yy * p.wc;
+    float* o = p.out + ((long)(b * p.h + 2 * yy + py) * p.w + 2 * xx + px) * 96;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *(f32x4*)(o + nt * 16 + q * 4) = acc[nt][pt];
+  }
+}
+
+// similar (B, L, hs, ws) <- P: channel = key j, pixel = query i (splitcam.py:106-108), for the unit-test entry point
+__global__ void att2_similar_kernel(const AttParams p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over B*L*L, query fastest
+  if (idx >= (long)p.B * p.L * p.L) return;
+  const int i = idx % p.L;
+  const long bj = idx / p.L;
+  const int j = bj % p.L, b = bj / p.L;
+  const int r = (i / p.ws) * p.wc + i % p.ws, s = (j / p.ws) * p.wc + j % p.ws;
+  p.similar[idx] = p.P[((size_t)b * p.R + r) * p.Rp + s];
+}
+
+static hipError_t launch_attention_v2(const AttParams& p, hipStream_t st) {
+  {
+    const long n = (long)p.B * p.h * p.w * 24;
+    ProfScope ps_(st, PL_ATT_PREP);
+    hipLaunchKernelGGL(att2_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(att2_transpose_kernel, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);
+  }
+  {
+    constexpr int NT = 4, PT = 4;
+    constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+    hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT>, LDS);
+    if (e != hipSuccess) return e;
+    dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 4.0 * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
+                    2.0 * p.B * (double)p.R * p.R * 384.0);
+    ProfScope ps_(st, PL_ATT_SCORE);
+    hipLaunchKernelGGL((att2_pair_kernel<NT, PT>), grid, dim3(256), LDS, st, p);
+  }
+  {
+    const long rows = (long)p.B * p.L;
+    ProfScope ps_(st, PL_ATT_SOFTMAX);
+    hipLaunchKernelGGL(att2_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  }
+  if (p.similar) {
+    const long n = (long)p.B * p.L * p.L;
+    ProfScope ps_(st, PL_LAYOUT);
+    hipLaunchKernelGGL(att2_similar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+  }
+  {
+    const long rows = (long)p.B * p.R;
+    ProfScope ps_(st, PL_ATT_BOXSUM);
+    hipLaunchKernelGGL(att2_boxsum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  }
+  {
+    constexpr int PT = 4;
+    constexpr int LDS = 2 * PT * 64 * 128 + 2 * 96 * 128;
+    hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT>, LDS);
+    if (e != hipSuccess) return e;
+    dim3 grid((p.R + PT * 64 - 1) / (PT * 64), 4, p.B);
+    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 4.0 * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
+                    2.0 * p.B * 4.0 * (double)p.R * p.Rp * 96.0);
+    ProfScope ps_(st, PL_ATT_PV);
+    hipLaunchKernelGGL((att2_pv_kernel<PT>), grid, dim3(256), LDS, st, p);
+  }
+  return hipGetLastError();
+}
+
+// SE_ATT_V1=1 selects the patch form (materialised L x L scores, K = 1536 / 4L) for A/B measurements
+hipError_t launch_attention(const AttParams& p, hipStream_t st) {
+  return p.E ? launch_attention_v2(p, st) : launch_attention_v1(p, st);
+}
+bool attention_v2_enabled() {
+  static const bool v1 = getenv("SE_ATT_V1") && atoi(getenv("SE_ATT_V1")) != 0;
+  return !v1;
 }
 
 }  // namespace se

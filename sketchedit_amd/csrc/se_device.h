@@ -96,6 +96,21 @@ DEVFN int xcd_tile(int bid, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Sub-pixel kernels (gen_deconv: 4 output parity classes over the same source tiles).  With the class in blockIdx.y the
+// dispatch is class-major and every class streams the whole source from HBM again (measured: 6.6x the algorithmic
+// bytes in winoup_kernel).  Here the grid is 1-D, 4 * round_up(ntiles, 8) blocks, and the four class blocks of a tile
+// are consecutive entries of ONE XCD's dispatch sequence (block ids b, b+8, b+16, b+24): they start together on four
+// CUs that share an L2, so the source tile comes from HBM once.  Returns false for the padding blocks.
+DEVFN bool class_tile(int bid, int ntiles, int xcd_remap, int& tile, int& cls) {
+  const int xcd = bid & 7, g = bid >> 3;
+  cls = g & 3;
+  const int b2 = ((g >> 2) << 3) | xcd;
+  if (b2 >= ntiles) return false;
+  tile = xcd_remap ? xcd_tile(b2, ntiles) : b2;
+  return true;
+}
+static inline int class_tile_grid(int ntiles) { return 4 * ((ntiles + 7) & ~7); }
+
 // ---- MFMA core ------------------------------------------------------------------------------------
 // One 32-k chunk for a wave tile of NT (rows: packed channels) x PT (cols: pixels) 16x16 tiles.
 // Wt: [NT*16][128 B] tile, Xt: this wave's [PT*16][128 B] tile, both with the 16-B slot of row r

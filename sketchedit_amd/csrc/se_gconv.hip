@@ -25,7 +25,10 @@ namespace se {
 // path stages through a buffer resource: per pixel row it keeps one byte offset and one tap-validity bit mask
 // (built once per workgroup), so a granule costs 3 VALU (bit extract, add, or) and an out-of-image tap is simply an
 // out-of-range offset, for which the hardware delivers zeros.
-template <int NT, int PT, bool MIXED, int WPS, bool FAST>
+// SPLIT: the workgroup owns only NT of the layer's row tiles -- group blockIdx.y; for the non-MIXED layouts a group is
+// NT/2 feature tiles plus their NT/2 gate tiles, so the gate stays a register epilogue.  Used with PT = 1 for grids
+// that would leave most CUs idle (one image): 6x (N=192) / 3x (N=96) more, shorter workgroups.
+template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT>
 __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   constexpr int PIX = PT * 64;
   constexpr int NP = NT * 16;
@@ -38,12 +41,24 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * PIX;
   // sub-pixel upsample form: this workgroup computes output pixels (2yy+py, 2xx+px); taps (a,b) in {0,1}^2 read
-  // source (yy + a - 1 + py, xx + b - 1 + px) with weights summed over the 3x3 taps that collapse onto it
-  const int py = p.up2 ? (int)(blockIdx.y >> 1) : 0, px = p.up2 ? (int)(blockIdx.y & 1) : 0;
+  // source (yy + a - 1 + py, xx + b - 1 + px) with weights summed over the 3x3 taps that collapse onto it.  The four
+  // class workgroups of a pixel tile sit side by side in one XCD's dispatch sequence (class_tile, se_device.h).
+  int tile_idx = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, cls = 0;
+  if (p.up2 && !class_tile((int)blockIdx.x, (p.total_pix + PIX - 1) / PIX, p.xcd, tile_idx, cls)) return;
+  const int tile_base = tile_idx * PIX;
+  const int py = cls >> 1, px = cls & 1;
   const int pady = p.up2 ? 1 - py : p.pad, padx = p.up2 ? 1 - px : p.pad;
-  const float* wbase = p.wpk + (p.up2 ? (size_t)blockIdx.y * p.nch * NP * 32 : 0);
+  const int npf = SPLIT ? p.np_full : NP;            // rows of one chunk of the packed weight image
+  const int grp = SPLIT ? (int)blockIdx.y : 0;
+  const float* wbase = p.wpk + (size_t)cls * p.nch * npf * 32;
+  // 8-row block `rbk` of this workgroup's W tile -> 8-row block of the layer's packed image
+  auto full_rbk = [&](int rbk) -> int {
+    if (!SPLIT) return rbk;
+    const int lt = rbk >> 1;
+    const int ft = MIXED ? grp * NT + lt : (lt < NT / 2 ? grp * (NT / 2) + lt : p.nf_full + grp * (NT / 2) + (lt - NT / 2));
+    return ft * 2 + (rbk & 1);
+  };
 
   // ---- row table: (batch, packed y0|x0) of every pixel row of the tile; invalid rows fail the bounds test
   const int HoWo = p.Ho * p.Wo;
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     } else if (q < NPIECE) {
       const int rbk = (q - NX) * 4 + w;
       if (rbk < NT * 2)
-        glds16_s(wbase + (size_t)ch * NP * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WBYTES + rbk * 1024);
+        glds16_s(wbase + (size_t)ch * npf * 32 + full_rbk(rbk) * 256, (unsigned)lane * 16u, lds_w + buf * WBYTES + rbk * 1024);
     }
   };
   auto stage_fast = [&](int ch, int buf) {
@@ -151,11 +166,11 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       glds16(g, xdst + (i * 4 + w) * 1024);
     }
     const unsigned wdst = lds_w + buf * WBYTES;
-    const float* wsrc = wbase + (size_t)ch * NP * 32 + lane * 4;
+    const float* wsrc = wbase + (size_t)ch * npf * 32 + lane * 4;
 #pragma unroll
     for (int j = 0; j < (NT * 2 + 3) / 4; ++j) {
       const int rbk = j * 4 + w;
-      if (rbk < NT * 2) glds16(wsrc + rbk * 256, wdst + rbk * 1024);
+      if (rbk < NT * 2) glds16(wsrc + full_rbk(rbk) * 256, wdst + rbk * 1024);
     }
   };
   auto stage = [&](int ch, int buf) {
@@ -204,11 +219,12 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   };
   if (!MIXED) {
     constexpr int NF = NT / 2;       // tiles [0,NF): features, [NF,NT): matching gates
+    const int nff = SPLIT ? p.nf_full : NF;
 #pragma unroll
     for (int nt = 0; nt < NF; ++nt) {
-      const int c0 = nt * 16 + q * 4;
+      const int c0 = (grp * NF + nt) * 16 + q * 4;
       const f32x4 bf = *(const f32x4*)(p.bias + c0);
-      const f32x4 bg = *(const f32x4*)(p.bias + NF * 16 + c0);
+      const f32x4 bg = *(const f32x4*)(p.bias + nff * 16 + c0);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
@@ -230,8 +246,8 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     // ds_bpermute exchange cost these narrow layers about as much as a third of their MFMAs.
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
-      const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
+      const int c0 = (grp * NT + nt) * 8 + (q & 1) * 4 + (q >> 1) * 2;
+      const f32x4 bq = *(const f32x4*)(p.bias + (grp * NT + nt) * 16 + q * 4);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
@@ -249,21 +265,20 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   }
 }
 
-template <int NT, int PT, bool MIXED, int WPS, bool FAST>
+template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT>
 static hipError_t launch_gconv_f(const GConvParams& p, hipStream_t st, int label) {
   constexpr int PIX = PT * 64;
   constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128;
   static_assert(PIX * 8 <= 2 * PIX * 128, "row table aliases the X buffers");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  {
+    hipError_t e = ensure_max_lds((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT>, LDS);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
-  const int grid = (p.total_pix + PIX - 1) / PIX;
+  const int tiles = (p.total_pix + PIX - 1) / PIX;
+  const int grid = p.up2 ? class_tile_grid(tiles) : tiles;
+  const int groups = SPLIT ? p.np_full / (NT * 16) : 1;
   ProfScope ps_(st, label);
-  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST>), dim3(grid, p.up2 ? 4 : 1), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT>), dim3(grid, groups), dim3(256), LDS, st, p);
   return hipGetLastError();
 }
 
@@ -273,10 +288,10 @@ static bool fast_eligible(const GConvParams& p) {
   return enabled && p.C0g == p.CG && !p.ushift && p.T <= 31 && p.magicKH * p.KW == p.T &&
          (long long)p.B * p.Hin * p.Win * p.C0 * 4 < (1ll << 31);
 }
-template <int NT, int PT, bool MIXED, int WPS>
+template <int NT, int PT, bool MIXED, int WPS, bool SPLIT = false>
 static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label) {
-  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true>(p, st, label)
-                          : launch_gconv_f<NT, PT, MIXED, WPS, false>(p, st, label);
+  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT>(p, st, label)
+                          : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT>(p, st, label);
 }
 
 // (A 3-stage LDS ring for the narrow MIXED shapes -- two chunks of DMA in flight, exact vmcnt waits -- was measured
@@ -296,6 +311,17 @@ static int variant_of(int cfg) {
 }
 
 hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
+  if (p.small_grid) {
+    // low-latency shapes: 64-pixel tiles; the wide layers also split their rows over blockIdx.y (one feature tile + its
+    // gate tile per workgroup): 6x / 3x more workgroups, each a sixth / third as long
+    switch (cfg) {
+      case GC_N192: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N192);
+      case GC_N96: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N96);
+      case GC_N48: return launch_gconv_t<3, 1, true, 4>(p, st, PL_GCONV_N48);
+      case GC_N24: return launch_gconv_t<2, 1, true, 4>(p, st, PL_GCONV_N24);
+    }
+    return hipErrorInvalidValue;
+  }
   const int var = variant_of(cfg);
   switch (cfg) {
     case GC_N192:

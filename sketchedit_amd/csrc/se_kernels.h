@@ -14,17 +14,22 @@ namespace se {
 // figures.  Off by default; when off the launch wrappers add nothing.
 // ---------------------------------------------------------------------------------------------
 enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL_WINO_N192, PL_WINO_N96, PL_WINO_UP96, PL_SMALL_CONV, PL_PACK, PL_COLREDUCE,
-                 PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
+                 PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_BOXSUM, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
 const char* prof_label_name(int l);
 struct Profiler {
-  struct Rec { int label; const char* name; double flops; double bytes; hipEvent_t a, b; };
+  struct Rec { int label; const char* name; double flops; double exec_flops; double bytes; hipEvent_t a, b; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;   // pre-created events (se_profile_enable), handed out two per launch
   size_t used = 0;
   bool on = false;
 };
 void set_profiler(Profiler* p);          // thread-local; set by the API under the ctx lock
-void set_launch_cost(double flops, double bytes, const char* name = nullptr);   // cost/name of the NEXT launch (consumed once)
+// cost/name of the NEXT launch (consumed once).  flops = algorithmic FLOPs of the layer as the reference defines it;
+// exec_flops = multiply-add FLOPs the kernel's MFMA pipe actually executes (Winograd / sub-pixel / space-to-depth forms
+// execute fewer); < 0: same as flops.  The roofline fraction is computed from exec_flops.
+void set_launch_cost(double flops, double bytes, const char* name = nullptr, double exec_flops = -1.0);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (device, kernel)
+hipError_t ensure_max_lds(const void* func, int bytes);
 
 // ---------------------------------------------------------------------------------------------
 // Gather-GEMM gated convolution (the hot kernel).
@@ -50,7 +55,7 @@ struct GConvParams {
   int div_hw_l, div_w_l;        // their shift counts
   int stride, dil, pad;
   int ushift;          // 1: source is read through a nearest x2 upsample (coords >> 1)
-  int up2;             // 1: sub-pixel form of nearest-x2 + 3x3: blockIdx.y = output parity class (py,px), a 2x2 conv
+  int up2;             // 1: sub-pixel form of nearest-x2 + 3x3: one workgroup = one output parity class (py,px), a 2x2 conv
                        //    on the source grid with pre-summed weights; (Ho,Wo) is then the SOURCE grid, (OH,OW) the output
   int OH, OW;
   int Hlim, Wlim;      // validity limits of the pre-shift tap coordinates
@@ -60,6 +65,10 @@ struct GConvParams {
   int act;             // 0 ELU, 1 ReLU
   int total_pix;       // B*Ho*Wo
   int xcd;             // 1: XCD-aware tile order (se_device.h xcd_tile)
+  int np_full;         // packed rows of the whole layer (row count of one chunk of wpk)
+  int nf_full;         // feature tiles of the whole layer (non-MIXED layouts: gates start at tile nf_full)
+  int small_grid;      // 1: low-latency launch shape (small pixel tiles; the packed rows split over blockIdx.y) for grids
+                       //    that would otherwise leave most of the 256 CUs idle (batch 1)
 };
 
 // magic numbers of se_device.h udiv_magic for divisor d >= 1
@@ -118,6 +127,11 @@ struct SmallConvParams {
   float* xnow;         // mode 2: NHWC4 next-stage input
   float* composed;     // mode 3: NCHW (B,3,H,W) (may be null)
   int no_mask_coarse;
+  // batch strides in floats (0 = dense): the packed output of SE_FLAG_PACKED_OUT is one (B,4,H,W) buffer, composed in
+  // planes 0-2 and the soft mask in plane 3 (one all-gather of the packed outputs)
+  long out_bs;         // of out_nchw (mode 0: the soft mask)
+  long mask_bs;        // of mask (mode 3: the soft mask)
+  long comp_bs;        // of composed
 };
 hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st);
 
@@ -154,7 +168,15 @@ struct AttParams {
   int B, h, w, hs, ws, L, Lp;
   float scale;         // softmax scale (10)
   float th;            // validity threshold (0.1)
+  // ---- space-to-depth form (se_attention.hip, "v2"): class grid hc x wc = h/2 x w/2, R = hc*wc rows, Rp = R rounded up to 32
+  int hc, wc, R, Rp;
+  float* xT;           // [B][4 classes][96][Rp]  workspace: x transposed per parity class (A operand of the P~.V GEMM)
+  float* E;            // [B][R][Rp] workspace: pixel-pair dot products E, later overwritten by P~
+  float* P;            // [B][R][Rp] workspace: softmax probabilities in class-grid indexing (row = query, column = key)
+  float* validR;       // [B][Rp]    workspace: key validity in class-grid indexing: 1 / 0, -1 where the position is not a key
+  float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
 };
-hipError_t launch_attention(const AttParams& p, hipStream_t st);
+hipError_t launch_attention(const AttParams& p, hipStream_t st);    // p.E != null: space-to-depth form, else the patch form
+bool attention_v2_enabled();
 
 }  // namespace se

@@ -4,29 +4,49 @@
 // host-side launch profiler.
 #include "se_device.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace se {
 
 // ---- profiler plumbing ----------------------------------------------------------------------------
 static thread_local Profiler* g_prof = nullptr;
-static thread_local double g_next_flops = 0.0, g_next_bytes = 0.0;
+static thread_local double g_next_flops = 0.0, g_next_bytes = 0.0, g_next_exec = 0.0;
 static thread_local const char* g_next_name = nullptr;
 void set_profiler(Profiler* p) { g_prof = p; }
-void set_launch_cost(double flops, double bytes, const char* name) { g_next_flops = flops; g_next_bytes = bytes; g_next_name = name; }
+void set_launch_cost(double flops, double bytes, const char* name, double exec_flops) {
+  g_next_flops = flops; g_next_bytes = bytes; g_next_name = name; g_next_exec = exec_flops < 0.0 ? flops : exec_flops;
+}
+
+hipError_t ensure_max_lds(const void* func, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_pair(dev, func);
+  if (done.count(key)) return hipSuccess;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert(key);
+  return e;
+}
 const char* prof_label_name(int l) {
   static const char* n[PL_COUNT] = {"gconv_n192", "gconv_n96", "gconv_n48", "gconv_n24", "wino_n192", "wino_n96", "wino_up96", "small_conv", "pack",
-                                    "colreduce", "att_prep", "att_score", "att_softmax", "att_pv", "layout"};
+                                    "colreduce", "att_prep", "att_score", "att_softmax", "att_boxsum", "att_pv", "layout"};
   return (l >= 0 && l < PL_COUNT) ? n[l] : "?";
 }
 
 ProfScope::ProfScope(hipStream_t s, int label) : st(s) {
   Profiler* p = g_prof;
-  const double fl = g_next_flops, by = g_next_bytes;
+  const double fl = g_next_flops, by = g_next_bytes, ex = g_next_exec;
   const char* nm = g_next_name;
-  g_next_flops = g_next_bytes = 0.0;
+  g_next_flops = g_next_bytes = g_next_exec = 0.0;
   g_next_name = nullptr;
   if (!p || !p->on) return;
   Profiler::Rec r;
-  r.label = label; r.name = nm; r.flops = fl; r.bytes = by;
+  r.label = label; r.name = nm; r.flops = fl; r.exec_flops = ex; r.bytes = by;
   // events come from a pool created at se_profile_enable(): creating them here cost ~10 us of host time per launch,
   // let the GPU run dry between kernels and inflated the measured durations of short kernels
   if (p->used + 2 > p->pool.size()) return;
@@ -80,7 +100,7 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p
   }
   if (p.mode == 0) {
     const float m = sigmoidf_(acc[0]);
-    p.out_nchw[idx] = m;
+    p.out_nchw[p.out_bs ? (long)b * p.out_bs + rem : idx] = m;
     if (p.hard) p.hard[idx] = m > 0.5f ? 1.f : 0.f;
     return;
   }
@@ -104,11 +124,12 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p
       o[3] = 0.f;
       *(f32x4*)(p.xnow + idx * 4) = o;
     } else if (p.mode == 3 && p.composed) {
-      const float m = p.mask[idx];
+      const float m = p.mask[p.mask_bs ? (long)b * p.mask_bs + rem : idx];
+      const long cb = p.comp_bs ? (long)b * p.comp_bs : (long)b * 3 * HW;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float im = p.img[((long)b * 3 + c) * HW + rem];
-        p.composed[((long)b * 3 + c) * HW + rem] = t[c] * m + im * (1.f - m);   // editline2_model.py:132
+        p.composed[cb + (long)c * HW + rem] = t[c] * m + im * (1.f - m);   // editline2_model.py:132
       }
     }
   }

@@ -360,11 +360,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 template <int NCHK>
 static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
   constexpr int LDS = 3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 24 KB + W ring 96 KB + source offsets
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wino_kernel<NCHK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  {
+    hipError_t e = ensure_max_lds((const void*)wino_kernel<NCHK>, LDS);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int grid = (p.total_tiles + 63) / 64;
   ProfScope ps_(st, PL_WINO_N192);

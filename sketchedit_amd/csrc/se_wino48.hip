@@ -327,11 +327,9 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
 
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
   constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 8 * 512 * 4 + (W48_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 48 KB + W ring 48 KB + source offsets
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wino48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  {
+    hipError_t e = ensure_max_lds((const void*)wino48_kernel, LDS);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int grid = (p.total_tiles + 127) / 128;
   ProfScope ps_(st, PL_WINO_N96);

@@ -6,7 +6,8 @@
 // 2x2 tile of class outputs (3x3 source pixels d):
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A,   B^T = [1 -1 0; 0 1 0; 0 -1 1]   G = [1 0; 1 1; 0 1]   A^T = [1 1 0; 0 1 1]
 // 9 transform positions x K=96 instead of 4 taps x K=96 per 4 outputs (16/9 fewer multiply-adds than the sub-pixel
-// form, 4x fewer than the reference-defined layer); every coefficient is 0 or +-1.  blockIdx.y = class.
+// form, 4x fewer than the reference-defined layer); every coefficient is 0 or +-1.  The four class workgroups of a tile
+// group run side by side on one XCD (class_tile, se_device.h) so that they share the source tile through its L2.
 // Structure, pipeline and epilogue as se_wino48.hip (96 MIXED rows, a wave = 3 row tiles x 32 tiles, 128 tiles per
 // workgroup, two staged granules per lane), loop as se_wino.hip (27 iterations = 9 positions x 3 chunks, fold at the
 // first chunk of the next position).  Source pixels whose B^T factor is structurally zero are not loaded.
@@ -27,10 +28,12 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chh = w & 1, tp = w >> 1;          // row half (3 MIXED tiles = 24 channels), tile pair (32 tiles)
-  const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
+  int tgrp, cls;                               // tile group and output parity class of this workgroup (se_device.h)
+  if (!class_tile((int)blockIdx.x, (p.total_tiles + TILES - 1) / TILES, p.xcd, tgrp, cls)) return;
+  const int tile_base = tgrp * TILES;
   const int tpi = p.th * p.tw;                 // tiles per image
-  const int py = (int)(blockIdx.y >> 1), px = (int)(blockIdx.y & 1);      // output parity class
-  const float* upk = p.upk + (size_t)blockIdx.y * NIT * 96 * 32;
+  const int py = cls >> 1, px = cls & 1;
+  const float* upk = p.upk + (size_t)cls * NIT * 96 * 32;
 
   // tile -> (batch, first class-grid (= source-grid) pixel of its 2x2 outputs)
   auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
@@ -263,15 +266,13 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
 
 hipError_t launch_winoup(const WinoParams& p, hipStream_t st) {
   constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 6 * 512 * 4;     // X ring 48 KB + W ring 48 KB + source offsets
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)winoup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  {
+    hipError_t e = ensure_max_lds((const void*)winoup_kernel, LDS);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
-  const int grid = (p.total_tiles + 127) / 128;
+  const int grid = class_tile_grid((p.total_tiles + 127) / 128);
   ProfScope ps_(st, PL_WINO_UP96);
-  hipLaunchKernelGGL(winoup_kernel, dim3(grid, 4), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL(winoup_kernel, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
 }
 

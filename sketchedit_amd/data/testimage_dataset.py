@@ -5,11 +5,12 @@ import os
 
 import numpy as np
 import torch
-import torch.utils.data
 from PIL import Image
 
+from .base_dataset import BaseDataset
 
-class TestImageDataset(torch.utils.data.Dataset):
+
+class TestImageDataset(BaseDataset):
     @staticmethod
     def modify_commandline_options(parser, is_train):
         for flag, req, default in (("--image_dirs", True, None), ("--mask_dirs", True, None),

@@ -1,6 +1,7 @@
 """Serving helpers for the inference path: the per-request pre/post-processing of the reference's demo
 (/root/reference/demo.py:39-73, `process_image`) and a small dynamic batcher for concurrent callers
-(demo.py:120 runs Flask with threaded=True, i.e. concurrent forwards on one model object).
+(demo.py:120 runs Flask with threaded=True, i.e. concurrent forwards on one model object),
+with one worker per GPU when several models are given.
 
 No web framework here -- the Flask UI is out of scope; these are the pieces of it that touch the hot path.
 """
@@ -45,19 +46,45 @@ def process_image(model, img, mask):
     return _to_image(generated, size_raw)
 
 
+def create_models_for_gpus(opt, gpu_ids=None):
+    """One EditLine2Model per GPU of this node (weights replicated, one se_ctx / stream / workspace each): the worker set
+    of a multi-GPU BatchingServer.  `gpu_ids` defaults to every visible device."""
+    import copy
+    import torch
+    from . import models
+    ids = list(range(torch.cuda.device_count())) if gpu_ids is None else list(gpu_ids)
+    out = []
+    for i in ids:
+        o = copy.copy(opt)
+        o.gpu_ids = [i]
+        with torch.cuda.device(i):
+            out.append(models.create_model(o).eval())
+    return out
+
+
 class BatchingServer:
     """Concurrent `submit(img, mask)` calls are grouped by working size and run as one forward per group
     (up to `max_batch` requests, waiting at most `max_wait_s` for company).  The forward treats the images of a
-    batch independently, so a request's result does not depend on what it was batched with."""
+    batch independently, so a request's result does not depend on what it was batched with.
 
-    def __init__(self, model, max_batch=32, max_wait_s=0.005):
-        self.model, self.max_batch, self.max_wait_s = model, max_batch, max_wait_s
+    `models` = one model per GPU (create_models_for_gpus): every model gets its own worker thread, all workers pull
+    groups from the one shared queue -- dynamic batching across the GPUs of the node; an idle GPU
+    takes the next group, so the load balances itself.  `model` = the single-GPU form."""
+
+    def __init__(self, model=None, max_batch=32, max_wait_s=0.005, models=None):
+        self.models = list(models) if models is not None else [model]
+        if not self.models or any(m is None for m in self.models):
+            raise ValueError("BatchingServer needs a model (or a list of models, one per GPU)")
+        self.model = self.models[0]
+        self.max_batch, self.max_wait_s = max_batch, max_wait_s
         self._lock = threading.Condition()
         self._queue = []          # (x, m, size_raw, slot)
         self._stop = False
         self.batches = []         # sizes of the batches that were run (observability / tests)
-        self._worker = threading.Thread(target=self._run, daemon=True)
-        self._worker.start()
+        self.batches_by_model = [0] * len(self.models)
+        self._workers = [threading.Thread(target=self._run, args=(k,), daemon=True) for k in range(len(self.models))]
+        for t in self._workers:
+            t.start()
 
     def submit(self, img, mask):
         x, m, size_raw = _to_tensors(img, mask)
@@ -66,7 +93,7 @@ class BatchingServer:
             if self._stop:
                 raise RuntimeError("server is closed")
             self._queue.append((x, m, size_raw, slot))
-            self._lock.notify()
+            self._lock.notify_all()
         slot["done"].wait()
         if slot["err"] is not None:
             raise slot["err"]
@@ -75,8 +102,9 @@ class BatchingServer:
     def close(self):
         with self._lock:
             self._stop = True
-            self._lock.notify()
-        self._worker.join()
+            self._lock.notify_all()
+        for t in self._workers:
+            t.join()
 
     def _take_group(self):
         """Oldest request's size decides the group; wait briefly for more requests of that size."""
@@ -87,7 +115,7 @@ class BatchingServer:
                 return None
             shape = tuple(self._queue[0][0].shape)
             deadline = time.monotonic() + self.max_wait_s
-            while sum(1 for q in self._queue if tuple(q[0].shape) == shape) < self.max_batch:
+            while self._queue and sum(1 for q in self._queue if tuple(q[0].shape) == shape) < self.max_batch:
                 left = deadline - time.monotonic()
                 if left <= 0 or self._stop:
                     break
@@ -97,18 +125,23 @@ class BatchingServer:
             self._queue = [q for q in self._queue if id(q) not in taken]
             return group
 
-    def _run(self):
+    def _run(self, k):
         import torch
+        model = self.models[k]
         while True:
             group = self._take_group()
             if group is None:
                 return
+            if not group:                 # another worker took the requests this one was waiting with
+                continue
             try:
                 x = torch.cat([q[0] for q in group], 0)
                 m = torch.cat([q[1] for q in group], 0)
                 with torch.no_grad():
-                    generated, _ = self.model({"image": x, "mask": m}, mode="inference")
-                self.batches.append(len(group))
+                    generated, _ = model({"image": x, "mask": m}, mode="inference")
+                with self._lock:
+                    self.batches.append(len(group))
+                    self.batches_by_model[k] += 1
                 for i, q in enumerate(group):
                     q[3]["out"] = _to_image(generated[i:i + 1], q[2])
             except Exception as e:      # deliver the failure to every waiting caller

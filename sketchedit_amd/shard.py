@@ -2,8 +2,9 @@
 
 Images are independent (no batch statistics; attention, K-normalisation and pooling are per sample --
 SURVEY.md 8e), so rank r runs rows [lo, hi) of the global batch with replicated weights and no exchange
-during the forward.  The only collective is the all-gather of the outputs (composed (B,3,H,W) and
-mask (B,1,H,W)); on the GPU box the backend is nccl = RCCL over xGMI, in the CPU tests it is gloo.
+during the forward.  The only collective is ONE all-gather of the packed outputs (B/n, 4, H, W) -- planes 0-2 the
+composite, plane 3 the soft mask (SE_FLAG_PACKED_OUT lets the last kernel write that layout directly); on the GPU box
+the backend is nccl = RCCL over xGMI, in the CPU tests it is gloo.
 """
 import torch
 import torch.distributed as dist
@@ -30,13 +31,17 @@ def gather_batch(local, group=None):
 
 
 def sharded_inference(forward, image, sketch, group=None):
-    """Run `forward(image_shard, sketch_shard) -> (composed, mask)` on this rank's rows of the global
-    batch and return the gathered global (composed, mask).  Requires batch % world == 0."""
+    """Run `forward(image_shard, sketch_shard)` on this rank's rows of the global batch and return the gathered global
+    (composed, mask).  `forward` returns either the packed (b,4,H,W) tensor (Engine.inference_packed) or a
+    (composed, mask) pair, which is packed here; one collective either way.  Requires batch % world == 0."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = image.shape[0]
     if n % world:
         raise ValueError("global batch %d is not a multiple of the world size %d" % (n, world))
     lo, hi = shard_range(n, world, rank)
-    composed, mask = forward(image[lo:hi].contiguous(), sketch[lo:hi].contiguous())
-    return gather_batch(composed, group), gather_batch(mask, group)
+    out = forward(image[lo:hi].contiguous(), sketch[lo:hi].contiguous())
+    packed = out if isinstance(out, torch.Tensor) else torch.cat([out[0], out[1]], 1)
+    full = gather_batch(packed, group)
+    c = full.shape[1] - 1
+    return full[:, :c], full[:, c:]

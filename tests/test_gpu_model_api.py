@@ -200,7 +200,101 @@ def test_test_py_script_end_to_end(tmp_path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main(argv)
+    # the same files through the oracle and the reference script's quantisation (test.py:25-27: no clamp, truncation)
+    from oracle import sketchedit_oracle as O
+    WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
     for n in names:
         out = np.asarray(Image.open(tmp_path / "results" / n))
         msk = np.asarray(Image.open(tmp_path / "masks" / n))
         assert out.shape == (64, 64, 3) and msk.shape == (64, 64)
+        arr = np.asarray(Image.open(tmp_path / "images" / n).convert("RGB"), dtype=np.float32).transpose(2, 0, 1) / 255.0
+        x = torch.from_numpy((arr - 0.5) / 0.5)[None]
+        e = np.asarray(Image.open(tmp_path / "edges" / n).convert("L"), dtype=np.float32)[None, None] / 255.0
+        ref = O.inference(WM, WG, x, torch.from_numpy((e > 0).astype(np.float32)))
+        want = ((ref["composed"] + 1) / 2 * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)
+        want_m = (ref["mask"] * 255).numpy().astype(np.uint8)[0, 0]
+        # fp32 noise of ~1e-6 can move a value across an integer boundary: at most one grey level, on a few pixels
+        dm = np.abs(msk.astype(int) - want_m.astype(int))
+        assert dm.max() <= 1 and (dm > 0).mean() < 0.01
+        if np.array_equal((msk > 127), (want_m > 127)):         # same hard mask (no threshold flip): same composite
+            d = np.abs(out.astype(int) - want.astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def test_module_prefixed_checkpoint_through_the_c_abi(golden_dir):
+    """A DataParallel-style state dict ('module.' prefix, util/util.py:221-222) loaded straight through se_load_weights
+    gives the reference's vectors; a truncated dict leaves the engine not ready."""
+    from sketchedit_amd._lib import Engine
+    g = dict(np.load(os.path.join(golden_dir, "e2e_64.npz")))
+    e = Engine(0)
+    sdM = {"module." + k: v for k, v in synth.make_state_dict("M", 0).items()}
+    sdG = {"module." + k: v for k, v in synth.make_state_dict("G", 0).items()}
+    e.load_state_dict("M", sdM)
+    assert not e.weights_ready()
+    e.load_state_dict("G", sdG)
+    assert e.weights_ready()
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    r = e.inference(torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda(), 1 | 2 | 16, visualize=True)
+    assert np.array_equal(r["hard"].cpu().numpy(), g["hard_mask"])
+    for k in ("composed", "mask", "coarse", "fine"):
+        assert float(np.abs(r[k].cpu().numpy() - g[k]).max()) < 1e-3, k
+    e.close()
+
+
+def test_serve_matches_oracle_pipeline(model):
+    """process_image (demo.py:39-73) against the same steps written with the ORACLE as the forward."""
+    from PIL import Image
+    from oracle import sketchedit_oracle as O
+    from sketchedit_amd import serve
+    rng = np.random.RandomState(11)
+    w, h = 83, 70
+    img = Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8))
+    sk = Image.fromarray(((rng.rand(h, w) < 0.01) * 255).astype(np.uint8))
+    got = np.asarray(serve.process_image(model, img, sk))
+    x = (torch.from_numpy(np.array(img.resize((80, 64))).transpose(2, 0, 1).astype(np.float32)) / 255 - 0.5) / 0.5
+    m = (torch.from_numpy(np.array(sk.resize((80, 64))).astype(np.float32)) > 0).float()
+    ref = O.inference(synth.make_state_dict("M", 0), synth.make_state_dict("G", 0), x[None], m[None, None])
+    gen = ((torch.clamp(ref["composed"], -1, 1) + 1) / 2 * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)
+    want = np.asarray(Image.fromarray(gen).resize(img.size))
+    with torch.no_grad():
+        vis = model({"image": x[None], "mask": m[None, None]}, mode="visualize")
+    if np.array_equal(vis["mask"].cpu().numpy(), ref["hard_mask"].numpy()):     # no threshold flip on this input
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+    assert got.shape == (h, w, 3)
+
+
+@pytest.mark.timeout(120)
+def test_serve_two_contexts_one_process(model, tmp_path_factory):
+    """Multi-GPU dispatch of the serving wrapper, exercised with what a 1-GPU box offers: two models (two se_ctx, two
+    workspaces) in one process, one worker thread each, one shared queue.  With a second GPU visible the second model
+    lives there (per-device kernel attributes, se_misc.hip ensure_max_lds)."""
+    import threading
+    from PIL import Image
+    from sketchedit_amd import models, serve
+    from sketchedit_amd.options.test_options import TestOptions
+    dev2 = 1 if torch.cuda.device_count() > 1 else 0
+    opt = TestOptions().parse(ARGV.format(d=tmp_path_factory.mktemp("out2")).replace("--gpu_ids 0", "--gpu_ids %d" % dev2).split(),
+                              quiet=True)
+    opt.isSkip = True
+    m2 = models.create_model(opt)
+    m2.netG.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()})
+    m2.netM.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()})
+    m2.eval()
+    torch.cuda.set_device(0)
+    rng = np.random.RandomState(5)
+    reqs = [(Image.fromarray(rng.randint(0, 255, (64, 72, 3), dtype=np.uint8)),
+             Image.fromarray(((rng.rand(64, 72) < 0.01) * 255).astype(np.uint8))) for _ in range(12)]
+    single = [serve.process_image(model, i, s) for i, s in reqs]
+    srv = serve.BatchingServer(models=[model, m2], max_batch=2, max_wait_s=0.001)
+    outs = [None] * len(reqs)
+
+    def worker(k):
+        outs[k] = srv.submit(*reqs[k])
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(len(reqs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    srv.close()
+    for a, b in zip(single, outs):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert sum(srv.batches) == len(reqs) and all(n > 0 for n in srv.batches_by_model)

@@ -65,6 +65,19 @@ def test_options_celeb_command_line(tmp_path):
         _lib.flags_from_opt(o)
 
 
+def test_options_demo_command_line_default_dataset_mode():
+    """demo.py:19 parses without --dataset_mode, i.e. with its default 'base' -> data/base_dataset.py BaseDataset."""
+    from sketchedit_amd import data
+    from sketchedit_amd.data.base_dataset import BaseDataset
+    from sketchedit_amd.data.testimage_dataset import TestImageDataset
+    from sketchedit_amd.options.test_options import TestOptions
+    o = TestOptions().parse("--name celeb --joint_train_inp --model editline2 --netG deepfillc2 --pool_type max "
+                            "--use_cam --which_epoch latest".split(), quiet=True)
+    assert o.dataset_mode == "base" and o.model == "editline2"
+    assert data.find_dataset_using_name("base") is BaseDataset and issubclass(TestImageDataset, BaseDataset)
+    assert len(BaseDataset()) == 0
+
+
 def test_registries_and_state_dict_contract(tmp_path):
     from sketchedit_amd import models
     from sketchedit_amd.models import networks
@@ -221,6 +234,60 @@ def test_batching_server_groups_by_size_and_preserves_results():
     srv.close()
     with pytest.raises(RuntimeError, match="closed"):
         srv.submit(*reqs[0])
+
+
+@pytest.mark.timeout(60)
+def test_batching_server_dispatches_over_several_models():
+    """BatchingServer(models=[one per GPU]): a shared queue, one worker per model; every request is answered exactly
+    once with its own result and, under load, every model gets work (dynamic batching across the GPUs)."""
+    import threading
+    import time
+    from PIL import Image
+    from sketchedit_amd import serve
+
+    class Fake:
+        def __init__(self, tag):
+            self.tag, self.calls, self.lock = tag, 0, threading.Lock()
+
+        def __call__(self, data, mode):
+            with self.lock:
+                self.calls += 1
+            time.sleep(0.03)
+            return data["image"] * 0.5, data["mask"]
+
+    rng = np.random.RandomState(7)
+    reqs = [(Image.fromarray(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8)),
+             Image.fromarray(((rng.rand(64, 64) < 0.01) * 255).astype(np.uint8))) for _ in range(24)]
+    want = [serve.process_image(Fake(0), i, s) for i, s in reqs]
+    fakes = [Fake(k) for k in range(4)]
+    srv = serve.BatchingServer(models=fakes, max_batch=2, max_wait_s=0.001)
+    outs = [None] * len(reqs)
+
+    def worker(k):
+        outs[k] = srv.submit(*reqs[k])
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(len(reqs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    srv.close()
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(want, outs))
+    assert sum(srv.batches) == len(reqs)
+    assert all(f.calls > 0 for f in fakes), [f.calls for f in fakes]
+
+
+def test_check_checkpoint_missing_key_not_hidden_by_suffix_match(tmp_path):
+    """A problem line that merely ENDS with a key name must not hide that the key itself is missing."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_check_ckpt2", os.path.join(root, "tools", "check_checkpoint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    M = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()}
+    M["wconv1.weight"] = M.pop("conv1.weight")          # 'unexpected key wconv1.weight' ends with 'conv1.weight'
+    M["module.xconv1.bias"] = M.pop("conv1.bias")
+    _, problems = mod.check_state_dict("M", M)
+    text = "\n".join(problems)
+    assert "missing key conv1.weight" in text and "missing key conv1.bias" in text
+    assert "unexpected key wconv1.weight" in text
 
 
 def test_check_checkpoint_tool(tmp_path):

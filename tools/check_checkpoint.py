@@ -30,20 +30,22 @@ def expected_shapes(net):
 def check_state_dict(net, sd):
     """-> (clean dict of fp32 numpy arrays, list of problems)."""
     want = expected_shapes(net)
-    clean, problems = {}, []
+    clean, problems, seen = {}, [], set()
     for k, v in sd.items():
         key = k[len("module."):] if k.startswith("module.") else k
         arr = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
         if key not in want:
             problems.append("unexpected key %s" % k)
-        elif tuple(arr.shape) != want[key]:
+            continue
+        seen.add(key)                       # present (possibly malformed): not "missing"
+        if tuple(arr.shape) != want[key]:
             problems.append("size mismatch for %s: %s, expected %s" % (k, tuple(arr.shape), want[key]))
         elif not np.isfinite(arr).all():
             problems.append("non-finite values in %s" % k)
         else:
             clean[key] = arr.astype(np.float32)
     for key in want:
-        if key not in clean and not any(p.endswith(key) or (" " + key + ":") in p for p in problems):
+        if key not in seen:
             problems.append("missing key %s" % key)
     return clean, problems
 
