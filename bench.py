@@ -25,6 +25,7 @@ Extra objects in the line:
 """
 import argparse
 import csv
+import faulthandler
 import glob
 import json
 import os
@@ -129,6 +130,7 @@ def pmc_traffic(argv_child, timeout_s=240):
 
 
 def main():
+    faulthandler.enable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -256,7 +258,7 @@ def main():
             if rank == 0:
                 g0 = (world - 1) * B
                 i1, s1 = synth.make_inputs(1, S, S, seed=1234, first_index=g0)
-                ll = eng.exec_flags(B, S, S, low_latency) != 0       # same execution mode as the sharded run
+                ll = eng.is_low_latency(B, S, S, low_latency)       # same execution mode as the sharded run
                 r1 = eng.inference(torch.from_numpy(i1).to(dev), torch.from_numpy(s1).to(dev), FLAGS, low_latency=ll)
                 ok = ok and torch.equal(r1["composed"], gathered[g0:g0 + 1, 0:3]) and torch.equal(r1["mask"], gathered[g0:g0 + 1, 3:4])
             f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -317,13 +319,24 @@ def main():
         WG = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()}
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         ref = O.inference(WM, WG, img_h[:1], sk_h[:1])
-        ll = eng.exec_flags(B, S, S, low_latency) != 0       # the execution mode of the timed run
+        ll = eng.is_low_latency(B, S, S, low_latency)       # the execution mode of the timed run
         r1 = eng.inference(img[:1].contiguous(), sk[:1].contiguous(), FLAGS, visualize=True, low_latency=ll)
         flips = int((r1["hard"].cpu() != ref["hard_mask"]).sum())
         parity = {"max_abs_composed": float((r1["composed"].cpu() - ref["composed"]).abs().max()),
                   "max_abs_mask": float((r1["mask"].cpu() - ref["mask"]).abs().max()),
                   "hard_mask_flips": flips, "image": 0, "tolerance": 1e-3 if args.dtype == "f32" else None,
                   "comparator": "fp32 oracle"}
+        if args.dtype == "bf16":
+            # the comparator of the bf16 path is the oracle's bf16 mode (same roundings, fp32 accumulation); netG is
+            # compared on the oracle's hard mask so that a threshold flip does not change its input
+            refb = O.inference(WM, WG, img_h[:1], sk_h[:1], act_dtype=torch.bfloat16)
+            hard = refb["hard_mask"].to(dev)
+            _, fine = eng.netG(img[:1].contiguous(), img[:1].contiguous(), hard, hard, sk[:1].contiguous(), FLAGS)
+            parity.update({"bf16_oracle": {"max_abs_mask": float((r1["mask"].cpu() - refb["mask"]).abs().max()),
+                                           "hard_mask_flip_fraction": float((r1["hard"].cpu() != refb["hard_mask"]).float().mean()),
+                                           "max_abs_fine_given_oracle_mask": float((fine.cpu() - refb["fine"]).abs().max()),
+                                           "mean_abs_fine_given_oracle_mask": float((fine.cpu() - refb["fine"]).abs().mean()),
+                                           "tolerance": "3e-2 max-abs, 3e-3 mean-abs (tests/test_gpu_bf16.py)"}})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -331,7 +344,7 @@ def main():
 
     if rank == 0:
         images = world * B * args.steps
-        ll_on = eng.exec_flags(B, S, S, low_latency) != 0
+        ll_on = eng.is_low_latency(B, S, S, low_latency)
         line = {
             "metric": "images/sec", "value": images / elapsed, "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

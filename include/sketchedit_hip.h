@@ -48,7 +48,12 @@ enum {
   SE_FLAG_GRAPH = 64,
   /* PACKED_OUT (se_inference only): composed_out points at ONE (B,4,H,W) buffer -- planes 0-2 the composite, plane 3
    * the soft mask (mask_out is ignored and may be NULL): the unit a batch-sharded caller all-gathers. */
-  SE_FLAG_PACKED_OUT = 128
+  SE_FLAG_PACKED_OUT = 128,
+  /* BF16 (BASELINE config 5): activations and conv weights are stored as bf16 and multiplied on the bf16 matrix
+   * pipe (v_mfma_f32_16x16x32_bf16) with fp32 accumulation; bias, activations, gate, softmax and composites stay
+   * fp32; the external tensors stay fp32 NCHW.  The comparator is the oracle's bf16 mode (oracle/sketchedit_oracle.py);
+   * the 1e-3 fp32 bound of the north star does not apply (stated tolerances: tests/test_gpu_bf16.py). */
+  SE_FLAG_BF16 = 256
 };
 
 /* replaces networks.create_network's .cuda() (models/networks/__init__.py:30-38) */
@@ -71,6 +76,10 @@ size_t se_workspace_bytes(se_ctx* ctx, int B, int H, int W);
  * mode='inference' where the value is unused). */
 int se_netM_forward(se_ctx* ctx, void* stream, const float* image, const float* sketch, float* mask_out,
                     float* maskim_out, void* workspace, size_t workspace_bytes, int B, int H, int W);
+
+/* the same with execution options (SE_FLAG_LOW_LATENCY, SE_FLAG_BF16) */
+int se_netM_forward_ex(se_ctx* ctx, void* stream, const float* image, const float* sketch, float* mask_out,
+                       float* maskim_out, void* workspace, size_t workspace_bytes, int B, int H, int W, int exec_flags);
 
 /* DeepFillC2Generator.forward (editline_g.py:119-221).  x,x2 (B,3,H,W); mask,mask2,guide (B,1,H,W);
  * coarse_out / fine_out (B,3,H,W), coarse_out may be NULL. */
@@ -109,8 +118,9 @@ int se_gated_conv2d(se_ctx* ctx, void* stream, const float* x, const float* w_ho
                     int B, int Cin, int H, int W, int Cout, int k, int stride, int rate, int act, int upsample);
 /* The same with the options the forwards use: a second source x1 of the virtual channel concat in front of conv11 /
  * allconv11 (editline_g.py:166-167,211) -- a tensor (B,Cin1,H,W), or with x1_is_vector a spatially constant per-image
- * vector (B,Cin1), still zero padded at the borders; w is (Cout, Cin+Cin1, k, k) -- and exec_flags = SE_FLAG_LOW_LATENCY
- * to run the layer in its small-grid launch shape.  x1 may be NULL. */
+ * vector (B,Cin1), still zero padded at the borders; w is (Cout, Cin+Cin1, k, k) -- and exec_flags: SE_FLAG_LOW_LATENCY
+ * runs the layer in its small-grid launch shape, SE_FLAG_BF16 on the bf16 path (x, x1 and w are rounded to bf16 on the
+ * way in, y is the bf16 result widened to fp32).  x1 may be NULL. */
 int se_gated_conv2d_ex(se_ctx* ctx, void* stream, const float* x, const float* x1, int x1_is_vector, const float* w_host,
                        const float* b_host, float* y, int B, int Cin, int Cin1, int H, int W, int Cout, int k, int stride,
                        int rate, int act, int upsample, int exec_flags);
@@ -118,6 +128,9 @@ int se_gated_conv2d_ex(se_ctx* ctx, void* stream, const float* x, const float* x
  * 203-207): x (B,96,h,w), mask_full (B,1,4h,4w) -> out (B,96,h,w); similar_out (B,L,hs,ws) may be NULL. */
 int se_attention(se_ctx* ctx, void* stream, const float* x, const float* mask_full, float* out, float* similar_out,
                  int B, int h, int w);
+/* the same with exec_flags (SE_FLAG_BF16: x is rounded to bf16 on the way in, out is the bf16 result widened to fp32) */
+int se_attention_ex(se_ctx* ctx, void* stream, const float* x, const float* mask_full, float* out, float* similar_out,
+                    int B, int h, int w, int exec_flags);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,18 @@ tests/test_oracle_golden.py).
 Every function cites the reference lines it restates (paths relative to
 /root/reference).  Weights are passed as a dict name -> tensor with the reference's
 checkpoint keys ('<layer>.weight' OIHW, '<layer>.bias').
+
+bf16 mode (BASELINE config 5: "bf16 MFMA path with fp32 accumulate").  The reference has no reduced-precision mode,
+so the comparator is DEFINED here and pinned against the reference run with the same roundings injected through
+module hooks (tests/golden/make_golden.py, e2e_64_bf16.npz): with `act_dtype=torch.bfloat16`
+  * every conv weight is rounded to bf16 (biases stay fp32: they are added in the fp32 epilogue),
+  * every tensor a conv reads and every gated-conv output is rounded to bf16 (round-to-nearest-even),
+  * inside a layer everything is fp32: products of bf16 values are exact in fp32 and the accumulation, bias, ELU,
+    sigmoid, tanh and the composites run in fp32,
+  * attention: keys x*rsqrt(.) rounded to bf16, scores / softmax in fp32, probabilities rounded to bf16, P.V
+    accumulated in fp32, result rounded to bf16.
+The roundings are points, not a bit-exact model of any kernel's summation order: parity against this mode is stated
+with a bf16-noise tolerance (tests/test_oracle_golden.py derives it from two equally valid rounding placements).
 """
 import torch
 import torch.nn.functional as F
@@ -24,7 +36,12 @@ def _t(v):
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
 
 
-def gated_conv(x, w, b, stride=1, rate=1, act="elu"):
+def _r(x, dt):
+    """Round to the storage dtype of the reduced-precision mode (no-op in fp32 mode)."""
+    return x if dt is None else x.to(dt).to(torch.float32)
+
+
+def gated_conv(x, w, b, stride=1, rate=1, act="elu", dt=None):
     """models/networks/utils.py:9-33 (gen_conv).
 
     conv2d with zero padding rate*(k-1)/2 and dilation `rate`; when Cout==3 or act is
@@ -33,27 +50,30 @@ def gated_conv(x, w, b, stride=1, rate=1, act="elu"):
     """
     k = w.shape[-1]
     pad = int(rate * (k - 1) / 2)
-    y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=rate)
+    y = F.conv2d(_r(x, dt), _r(w, dt), b, stride=stride, padding=pad, dilation=rate)
     cout = w.shape[0]
     if cout == 3 or act is None:
         return y
     f, g = y[:, : cout // 2], y[:, cout // 2:]
     f = F.elu(f) if act == "elu" else torch.relu(f)
-    return f * torch.sigmoid(g)
+    return _r(f * torch.sigmoid(g), dt)
 
 
-def gated_deconv(x, w, b):
+def gated_deconv(x, w, b, dt=None):
     """models/networks/utils.py:35-51 (gen_deconv): nearest x2 upsample then gen_conv(k=3)."""
     x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)  # out[i,j] = in[i//2, j//2]
-    return gated_conv(x, w, b, 1, 1, "elu")
+    return gated_conv(x, w, b, 1, 1, "elu", dt)
+
+
+_DT = [None]      # storage dtype of the forward being evaluated (set by netM_forward / netG_forward)
 
 
 def _L(W, x, name, stride=1, rate=1, act="elu"):
-    return gated_conv(x, _t(W[name + ".weight"]), _t(W[name + ".bias"]), stride, rate, act)
+    return gated_conv(x, _t(W[name + ".weight"]), _t(W[name + ".bias"]), stride, rate, act, _DT[0])
 
 
 def _D(W, x, name):
-    return gated_deconv(x, _t(W[name + ".weight"]), _t(W[name + ".bias"]))
+    return gated_deconv(x, _t(W[name + ".weight"]), _t(W[name + ".bias"]), _DT[0])
 
 
 def _encoder(W, x, p, c3=True):
@@ -84,26 +104,30 @@ def _decoder(W, x, p, final_act):
     return torch.tanh(x) if final_act == "tanh" else torch.sigmoid(x)
 
 
-def netM_forward(W, x, guide, want_image=True):
+def netM_forward(W, x, guide, want_image=True, act_dtype=None):
     """models/networks/editline2_g.py:59-94 (MDGenerator.forward) -> (mask, mask_image).
 
     Quirk kept: the image decoder consumes conv9's output, the mask decoder conv10's
     (editline2_g.py:76-77).
     """
     x, guide = _t(x), _t(guide)
-    xin = torch.cat([x, guide], 1)
-    x9, x10 = _encoder(W, xin, "conv")
-    img = _decoder(W, x9, "conv", "tanh") if want_image else None
-    mask = _decoder(W, x10, "conv_mask_", "sigmoid")
+    _DT[0] = act_dtype
+    try:
+        xin = torch.cat([x, guide], 1)
+        x9, x10 = _encoder(W, xin, "conv")
+        img = _decoder(W, x9, "conv", "tanh") if want_image else None
+        mask = _decoder(W, x10, "conv_mask_", "sigmoid")
+    finally:
+        _DT[0] = None
     return mask, img
 
 
-def attention_scores(x, mask_s, scale=10.0, th=0.1):
+def attention_scores(x, mask_s, scale=10.0, th=0.1, dt=None):
     """models/networks/splitcam.py:37-108 (ReduceContextAttentionP1, patch 4, stride 2, pd 0,
     is_th, norm_type 1) with f = b = x.  Returns softmax scores (B, L_keys, hs, ws)."""
     B, C, h, w = x.shape
     valid = 1.0 - mask_s
-    xn = x / torch.sqrt((x * x).sum(3, keepdim=True).sum(2, keepdim=True) + 1e-8)  # :40
+    xn = _r(x / torch.sqrt((x * x).sum(3, keepdim=True).sum(2, keepdim=True) + 1e-8), dt)  # :40
     K = F.unfold(xn, 4, stride=2)                     # (B, C*16, L)  :42
     Q = F.unfold(x, 4, stride=2)                      # queries: raw patches (batch_conv2d :69)
     mk = F.unfold(valid, 4, stride=2)                 # (B, 16, L)    :49-53
@@ -115,26 +139,35 @@ def attention_scores(x, mask_s, scale=10.0, th=0.1):
     return P.view(B, -1, hs, ws)
 
 
-def attention_reconstruct(P, x):
+def attention_reconstruct(P, x, dt=None):
     """models/networks/splitcam.py:132-153 (ReduceContextAttentionP2, mk=False, pd 0):
     transposed conv with the raw patches as kernels == P^T V then overlap-add, no
     normalisation by the overlap count."""
     B, C, h, w = x.shape
     V = F.unfold(x, 4, stride=2)                      # (B, C*16, Lk)
-    Pm = P.reshape(B, P.shape[1], -1)                 # (B, Lk, Lq)
+    Pm = _r(P, dt).reshape(B, P.shape[1], -1)         # (B, Lk, Lq)
     O = torch.bmm(V, Pm)                              # (B, C*16, Lq)
-    return F.fold(O, (h, w), 4, stride=2)
+    return _r(F.fold(O, (h, w), 4, stride=2), dt)
 
 
-def contextual_attention(x, mask_full):
+def contextual_attention(x, mask_full, dt=None):
     """editline_g.py:203-207."""
     mask_s = F.avg_pool2d(mask_full, 4, 4)
-    P = attention_scores(x, mask_s)
-    return attention_reconstruct(P, x), P
+    P = attention_scores(x, mask_s, dt=dt)
+    return attention_reconstruct(P, x, dt), P
 
 
 def netG_forward(W, x, x2, mask, mask2, guide, use_cam=True, pool_type="max",
-                 no_mask_cc=False, no_mask_coarse=False, joint_train_inp=True, taps=None):
+                 no_mask_cc=False, no_mask_coarse=False, joint_train_inp=True, taps=None, act_dtype=None):
+    _DT[0] = act_dtype
+    try:
+        return _netG_forward(W, x, x2, mask, mask2, guide, use_cam, pool_type, no_mask_cc, no_mask_coarse,
+                             joint_train_inp, taps, act_dtype)
+    finally:
+        _DT[0] = None
+
+
+def _netG_forward(W, x, x2, mask, mask2, guide, use_cam, pool_type, no_mask_cc, no_mask_coarse, joint_train_inp, taps, dt):
     """models/networks/editline_g.py:119-221 (DeepFillC2Generator.forward) -> (coarse, fine).
 
     `taps` (optional dict) receives intermediates for localising a mismatch.
@@ -186,7 +219,7 @@ def netG_forward(W, x, x2, mask, mask2, guide, use_cam=True, pool_type="max",
     if taps is not None:
         taps["pmconv6"] = p
     if use_cam:
-        p, P = contextual_attention(p, mask)
+        p, P = contextual_attention(p, mask, dt)
         if taps is not None:
             taps["similar"] = P
             taps["attn_out"] = p
@@ -197,7 +230,7 @@ def netG_forward(W, x, x2, mask, mask2, guide, use_cam=True, pool_type="max",
     return stage1, stage2
 
 
-def inference(WM, WG, image, sketch, **flags):
+def inference(WM, WG, image, sketch, act_dtype=None, **flags):
     """models/editline2_model.py:128-133 + generate_fake :338-370 (eval mode).
 
     Returns dict(composed, mask, hard_mask, coarse, fine).  composed uses the SOFT mask
@@ -205,8 +238,8 @@ def inference(WM, WG, image, sketch, **flags):
     """
     image, sketch = _t(image), _t(sketch)
     with torch.no_grad():
-        mask, mask_image = netM_forward(WM, image, sketch)
+        mask, mask_image = netM_forward(WM, image, sketch, act_dtype=act_dtype)
         hard = (mask > 0.5).float()
-        coarse, fine = netG_forward(WG, image, image, hard, hard, sketch, **flags)
+        coarse, fine = netG_forward(WG, image, image, hard, hard, sketch, act_dtype=act_dtype, **flags)
         composed = fine * mask + image * (1 - mask)
     return dict(composed=composed, mask=mask, mask_image=mask_image, hard_mask=hard, coarse=coarse, fine=fine)

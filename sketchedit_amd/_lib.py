@@ -19,14 +19,15 @@ SOURCES = ["se_gconv.hip", "se_wino.hip", "se_wino48.hip", "se_wino_up.hip", "se
 
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
-FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT = 32, 64, 128          # execution options (include/sketchedit_hip.h)
+FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT, FLAG_BF16 = 32, 64, 128, 256   # execution options (include/sketchedit_hip.h)
 # calls of at most this many pixels (two 256x256 images) run in the low-latency mode unless the caller says otherwise
 LOW_LATENCY_MAX_PIXELS = 2 * 256 * 256
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
-           "se_workspace_bytes", "se_netM_forward", "se_netG_forward", "se_inference", "se_gated_conv2d",
-           "se_gated_conv2d_ex", "se_attention", "se_quantize_u8", "se_profile_enable", "se_profile_report"]
+           "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_inference", "se_gated_conv2d",
+           "se_gated_conv2d_ex", "se_attention", "se_attention_ex", "se_quantize_u8", "se_profile_enable",
+           "se_profile_report"]
 
 
 class SketchEditHipError(RuntimeError):
@@ -79,6 +80,8 @@ def load_library():
         lib.se_workspace_bytes.restype = sz
         lib.se_netM_forward.argtypes = [vp, vp, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci]
         lib.se_netM_forward.restype = ci
+        lib.se_netM_forward_ex.argtypes = [vp, vp, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
+        lib.se_netM_forward_ex.restype = ci
         lib.se_netG_forward.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
         lib.se_netG_forward.restype = ci
         lib.se_inference.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
@@ -89,6 +92,8 @@ def load_library():
         lib.se_gated_conv2d_ex.restype = ci
         lib.se_attention.argtypes = [vp, vp, c_f, c_f, c_f, c_f, ci, ci, ci]
         lib.se_attention.restype = ci
+        lib.se_attention_ex.argtypes = [vp, vp, c_f, c_f, c_f, c_f, ci, ci, ci, ci]
+        lib.se_attention_ex.restype = ci
         lib.se_quantize_u8.argtypes = [vp, vp, c_f, c_f, vp, vp, ci, ci, ci]
         lib.se_quantize_u8.restype = ci
         lib.se_profile_enable.argtypes = [vp, ci]
@@ -159,6 +164,8 @@ class Engine:
         self._ws = None
         self._ws_lock = threading.Lock()
         self._ws_stream = None
+        self._graph_stream = None
+        self.precision = "f32"     # "bf16": BASELINE config 5 (bf16 storage + MFMA, fp32 accumulate); see set_precision
         self._static = {}          # graph mode: per-shape input copies and output buffers (stable pointers)
 
     def close(self):
@@ -222,9 +229,9 @@ class Engine:
         ws = self.workspace(B, H, W)
         mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=image.device)
         mim = torch.empty((B, 3, H, W), dtype=torch.float32, device=image.device) if want_image else None
-        if self.lib.se_netM_forward(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(mask), _ptr(mim),
-                                    _ptr(ws), ws.numel(), B, H, W):
-            self._err("se_netM_forward")
+        if self.lib.se_netM_forward_ex(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(mask), _ptr(mim),
+                                       _ptr(ws), ws.numel(), B, H, W, FLAG_BF16 if self.precision == "bf16" else 0):
+            self._err("se_netM_forward_ex")
         return mask, mim
 
     def netG(self, x, x2, mask, mask2, guide, flags):
@@ -234,16 +241,27 @@ class Engine:
         ws = self.workspace(B, H, W)
         coarse = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
         fine = torch.empty_like(coarse)
+        flags = (flags & 31) | (FLAG_BF16 if self.precision == "bf16" else 0)
         if self.lib.se_netG_forward(self.h, self._stream(), _ptr(x), _ptr(x2), _ptr(mask), _ptr(mask2), _ptr(guide),
                                     _ptr(coarse), _ptr(fine), _ptr(ws), ws.numel(), B, H, W, flags):
             self._err("se_netG_forward")
         return coarse, fine
 
+    def set_precision(self, precision):
+        """'f32' (default; the north star's 1e-3 parity bound applies) or 'bf16' (SE_FLAG_BF16 on every forward)."""
+        if precision not in ("f32", "bf16"):
+            raise ValueError(precision)
+        self.precision = precision
+
+    @staticmethod
+    def is_low_latency(B, H, W, low_latency=None):
+        """The low-latency mode is chosen by call size unless forced (True / False)."""
+        return B * H * W <= LOW_LATENCY_MAX_PIXELS if low_latency is None else bool(low_latency)
+
     def exec_flags(self, B, H, W, low_latency=None, graph=False):
-        """Execution-option bits for a call: low-latency mode is chosen by size unless forced (True / False)."""
-        if low_latency is None:
-            low_latency = B * H * W <= LOW_LATENCY_MAX_PIXELS
-        return (FLAG_LOW_LATENCY if low_latency else 0) | (FLAG_GRAPH if graph else 0)
+        """Execution-option bits for a call."""
+        return (FLAG_LOW_LATENCY if self.is_low_latency(B, H, W, low_latency) else 0) | (FLAG_GRAPH if graph else 0) | \
+            (FLAG_BF16 if self.precision == "bf16" else 0)
 
     def inference(self, image, sketch, flags, visualize=False, out=None, low_latency=None, graph=False):
         """-> dict(composed, mask[, hard, maskim, coarse, fine]).  `out` may hold preallocated composed/mask.
@@ -278,10 +296,24 @@ class Engine:
             r = dict(st["outs"])
         else:
             r = new_outputs(out)
-        if self.lib.se_inference(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(r["composed"]), _ptr(r["mask"]),
-                                 _ptr(r.get("hard")), _ptr(r.get("maskim")), _ptr(r.get("coarse")), _ptr(r.get("fine")),
-                                 _ptr(ws), ws.numel(), B, H, W, flags):
-            self._err("se_inference")
+        def call(stream):
+            if self.lib.se_inference(self.h, stream, _ptr(image), _ptr(sketch), _ptr(r["composed"]), _ptr(r["mask"]),
+                                     _ptr(r.get("hard")), _ptr(r.get("maskim")), _ptr(r.get("coarse")), _ptr(r.get("fine")),
+                                     _ptr(ws), ws.numel(), B, H, W, flags):
+                self._err("se_inference")
+
+        if not graph:
+            call(self._stream())
+            return r
+        # stream capture is not permitted on the legacy default stream: graph-mode forwards run on a stream of their
+        # own, ordered after / before the caller's current stream
+        cur = torch.cuda.current_stream(self.device)
+        if self._graph_stream is None:
+            self._graph_stream = torch.cuda.Stream(device=self.device)
+        gs = self._graph_stream
+        gs.wait_stream(cur)
+        call(ctypes.c_void_p(gs.cuda_stream))
+        cur.wait_stream(gs)
         return r
 
     def inference_packed(self, image, sketch, flags, out, low_latency=None):
@@ -309,7 +341,7 @@ class Engine:
         return json.loads(buf.value.decode())
 
     # ---- per-op entry points (unit tests) --------------------------------------------------------
-    def gated_conv2d(self, x, w, b, stride=1, rate=1, act="elu", upsample=False, x1=None, low_latency=False):
+    def gated_conv2d(self, x, w, b, stride=1, rate=1, act="elu", upsample=False, x1=None, low_latency=False, bf16=False):
         """gen_conv / gen_deconv on x, or on the virtual concat cat([x, x1]) where x1 is a (B,C1,H,W) tensor or a
         (B,C1) per-image vector (broadcast over the image, zero padded at the borders)."""
         import torch
@@ -332,7 +364,7 @@ class Engine:
         if self.lib.se_gated_conv2d_ex(self.h, self._stream(), _ptr(x), _ptr(x1), int(x1 is not None and x1.dim() == 2),
                                        w.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), _ptr(y),
                                        B, Cin, Cin1, H, W, Cout, k, stride, rate, acode, int(upsample),
-                                       FLAG_LOW_LATENCY if low_latency else 0):
+                                       (FLAG_LOW_LATENCY if low_latency else 0) | (FLAG_BF16 if bf16 else 0)):
             self._err("se_gated_conv2d_ex")
         return y
 
@@ -347,7 +379,7 @@ class Engine:
             self._err("se_quantize_u8")
         return rgb, m8
 
-    def attention(self, x, mask_full, want_similar=False):
+    def attention(self, x, mask_full, want_similar=False, bf16=False):
         import torch
         _check_dev(x, mask_full)
         B, C, h, w = x.shape
@@ -355,6 +387,7 @@ class Engine:
         hs, ws = (h - 4) // 2 + 1, (w - 4) // 2 + 1
         out = torch.empty_like(x)
         sim = torch.empty((B, hs * ws, hs, ws), dtype=torch.float32, device=x.device) if want_similar else None
-        if self.lib.se_attention(self.h, self._stream(), _ptr(x), _ptr(mask_full), _ptr(out), _ptr(sim), B, h, w):
-            self._err("se_attention")
+        if self.lib.se_attention_ex(self.h, self._stream(), _ptr(x), _ptr(mask_full), _ptr(out), _ptr(sim), B, h, w,
+                                    FLAG_BF16 if bf16 else 0):
+            self._err("se_attention_ex")
         return (out, sim) if want_similar else out

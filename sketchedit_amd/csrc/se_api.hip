@@ -72,6 +72,9 @@ struct Layer {
   float* d_b = nullptr;
   float* d_u = nullptr;       // Winograd-transformed weights (eligible layers only)
   float* d_ub = nullptr;      // bias in the row order of the 48 -> 96 Winograd kernel (MIXED tiles)
+  // bf16 image (BASELINE config 5): same row order and slot swizzle, 64 bf16 k-values per 128-byte row, 8-channel granules
+  float* d_w16 = nullptr;
+  int nch16 = 0, CGp16 = 0;
 };
 
 // ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
@@ -136,6 +139,7 @@ struct se_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dry = false;
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
+  bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
   Profiler prof;
   struct Peaks { size_t main, side; };
   std::map<std::vector<long long>, Peaks> peaks;      // dry-run arena peaks per (B, H, W, flags, outputs wanted)
@@ -260,6 +264,70 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
   if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
+  return 0;
+}
+
+// fp32 -> bf16, round to nearest even (the rounding of v_cvt_pk_bf16_f32 and of torch's .to(bfloat16))
+unsigned short bf16_bits(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+float bf16_round(float f) {
+  const unsigned u = (unsigned)bf16_bits(f) << 16;
+  float r;
+  memcpy(&r, &u, 4);
+  return r;
+}
+
+// bf16 image of a gated conv: [class][chunk of 64 k][NP rows][64 bf16], k = flattened (tap, packed input channel) with the
+// channels of a tap padded to a multiple of 8 (one 16-byte granule = 8 channels); slot s of row n at s ^ ((n>>1)&7).
+// The sub-pixel sums of gen_deconv are formed in fp32 and rounded once.
+int pack_layer16(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
+  const LayerDef& d = L.def;
+  const int G = d.cout / 2;
+  const int cfg = choose_cfg(G);
+  if (cfg < 0 || (G % 4)) return fail(c, "layer %s: unsupported gated width %d", d.name, G);
+  const int NP = gconv_np(cfg);
+  const int Cp = (int)cin_map.size();          // packed channels per tap (multiple of 8)
+  const bool up2 = d.up != 0;
+  const int KW = up2 ? 2 : d.k;
+  const int T = KW * KW;
+  const int K = T * Cp;
+  const int nch = (K + 63) / 64;
+  const int ncls = up2 ? 4 : 1;
+  std::vector<unsigned short> img((size_t)ncls * nch * NP * 64, 0);
+  auto lo = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2); };
+  auto hi = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2); };
+  for (int cls = 0; cls < ncls; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    for (int n = 0; n < NP; ++n) {
+      const int oc = out_channel_of_row(cfg, n, G, d.cout);
+      if (oc < 0) continue;
+      for (int kf = 0; kf < K; ++kf) {
+        const int tap = kf / Cp, pc = kf % Cp;
+        const int ic = cin_map[pc];
+        if (ic < 0) continue;
+        const int ty = tap / KW, tx = tap % KW;
+        float v = 0.f;
+        if (up2) {
+          for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
+            for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx) v += L.w[(((size_t)oc * d.cin + ic) * 3 + ky) * 3 + kx];
+        } else {
+          v = L.w[(((size_t)oc * d.cin + ic) * d.k + ty) * d.k + tx];
+        }
+        const int ch = kf / 64, kin = kf % 64, s_ = kin / 8, e = kin % 8;
+        const int ps = s_ ^ ((n >> 1) & 7);
+        img[(((size_t)cls * nch + ch) * NP + n) * 64 + ps * 8 + e] = bf16_bits(v);
+      }
+    }
+  }
+  if (L.d_w16) (void)hipFree(L.d_w16);
+  HIPCHK(c, hipMalloc(&L.d_w16, img.size() * 2));
+  HIPCHK(c, hipMemcpy(L.d_w16, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  L.nch16 = nch; L.CGp16 = Cp / 8;
   return 0;
 }
 
@@ -399,6 +467,11 @@ int pack_small(se_ctx* c, Layer& L) {
   HIPCHK(c, hipMalloc(&L.d_b, d.cout * 4));
   HIPCHK(c, hipMemcpy(L.d_w, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(L.d_b, L.b.data(), d.cout * 4, hipMemcpyHostToDevice));
+  // bf16 mode: the same fp32 kernel with bf16-rounded weights (every conv weight is rounded in that mode)
+  for (auto& v : img) v = bf16_round(v);
+  if (L.d_w16) (void)hipFree(L.d_w16);
+  HIPCHK(c, hipMalloc(&L.d_w16, img.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_w16, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   L.packed = true;
   return 0;
 }
@@ -410,9 +483,28 @@ std::vector<int> identity_map(int cin) {
   return m;
 }
 
+std::vector<int> identity_map8(int cin) {      // bf16: channels of a tap padded to whole 8-channel granules
+  const int Cp = (cin + 7) & ~7;
+  std::vector<int> m(Cp, -1);
+  for (int i = 0; i < cin; ++i) m[i] = i;
+  return m;
+}
+
 int pack_net_layer(se_ctx* c, Layer& L) {
   const LayerDef& d = L.def;
   if (d.act == ACT_NONE) return pack_small(c, L);
+  {
+    // bf16 images: conv16's 12 gated outputs are stored with a 16-channel stride, so conv17 is not a gated layer and
+    // everything else reads whole granules
+    if (std::string(d.name) == "wconv1" && d.cin == 5) {
+      Layer& J = c->wconv1_j4;
+      J.def = d; J.w = L.w; J.b = L.b; J.have_w = J.have_b = true;
+      const int rc = pack_layer16(c, J, std::vector<int>{0, 1, 2, 4, -1, -1, -1, -1});
+      if (rc) return rc;
+    }
+    const int rc = pack_layer16(c, L, identity_map8(d.cin));
+    if (rc) return rc;
+  }
   std::vector<int> m;
   if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
   else m = identity_map(d.cin);
@@ -427,6 +519,47 @@ int pack_net_layer(se_ctx* c, Layer& L) {
   return pack_layer(c, L, m);
 }
 
+// ---- bf16 mode: every gated conv is the direct gather-GEMM on v_mfma_f32_16x16x32_bf16 (se_gconv.hip, BF16) -----------
+// (The Winograd transforms would have to run in fp32 on bf16 data and round the transformed tiles again; at 16x the
+// MFMA rate the layers are bound by the LDS fill, not by multiply-adds, so there is nothing for them to buy.)
+int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const float* src1, int C1, int src1_vec, float* dst,
+                int B, int Hin, int Win, int Ho, int Wo, int pad) {
+  const LayerDef& d = L.def;
+  if (!L.d_w16) return fail(c, "layer %s: no bf16 weight image", d.name);
+  if ((C0 + C1) != L.CGp16 * 8) return fail(c, "layer %s: bf16 source channels %d+%d != packed %d", d.name, C0, C1, L.CGp16 * 8);
+  GConvParams p;
+  memset(&p, 0, sizeof p);
+  p.bf16 = 1;
+  p.src0 = src0; p.src1 = src1 ? src1 : src0; p.wpk = L.d_w16; p.bias = L.d_b; p.dst = dst; p.zeros = c->zeros;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Ho = d.up ? Hin : Ho; p.Wo = d.up ? Win : Wo;
+  p.up2 = d.up ? 1 : 0; p.OH = Ho; p.OW = Wo;
+  p.C0 = C0; p.C1 = C1 ? C1 : C0; p.C0g = C0 / 8; p.CG = L.CGp16;
+  const int KW = d.up ? 2 : d.k;
+  p.T = L.T; p.KW = KW; p.stride = d.stride; p.dil = d.rate; p.pad = pad;
+  p.magicCG = (65536 + L.CGp16 - 1) / L.CGp16; p.magicKW = 256 / KW + 1; p.magicKH = L.T / KW;
+  for (int gi = 0; gi < L.nch16 * 8 + 8; ++gi)
+    if (((gi * p.magicCG) >> 16) != gi / L.CGp16) return fail(c, "layer %s: magic division check failed", d.name);
+  for (int t = 0; t <= L.T + 8; ++t)
+    if (((t * p.magicKW) >> 8) != t / KW) return fail(c, "layer %s: magic tap division check failed", d.name);
+  const int Gs = (L.G + 7) & ~7;                 // stored channel stride of the output
+  if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) >= 2147483648.0 || (double)B * Ho * Wo * Gs >= 2147483648.0)
+    return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
+  for (int j = 0; j < p.magicKH; ++j) p.rep |= 1u << (j * KW);
+  udiv_magic_host((unsigned)(p.Ho * p.Wo), &p.div_hw_m, &p.div_hw_l);
+  udiv_magic_host((unsigned)p.Wo, &p.div_w_m, &p.div_w_l);
+  p.Hlim = Hin; p.Wlim = Win;
+  p.src1_vec = src1_vec; p.nch = L.nch16; p.G = Gs; p.act = d.act; p.total_pix = B * p.Ho * p.Wo;
+  p.xcd = xcd_remap_enabled();
+  p.np_full = L.NP; p.nf_full = L.NP / 32; p.small_grid = c->low_latency ? 1 : 0;
+  {
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k;
+    const double exec = 2.0 * (double)B * p.Ho * p.Wo * (d.up ? 4.0 : 1.0) * L.NP * (L.nch16 * 64.0);
+    set_launch_cost(alg, 2.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name, exec);
+  }
+  HIPCHK(c, launch_gconv(L.cfg, p, c->st));
+  return 0;
+}
+
 // ---- launching one gated conv -----------------------------------------------------------------------
 int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float* src1, int C1, int src1_vec, float* dst,
               int B, int Hin, int Win, int* Ho_, int* Wo_) {
@@ -439,6 +572,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   if (Wo_) *Wo_ = Wo;
   if (c->dry) return 0;
   if (!L.packed) return fail(c, "layer %s: weights not loaded", d.name);
+  if (c->bf16) return run_gconv16(c, L, src0, C0, src1, C1, src1_vec, dst, B, Hin, Win, Ho, Wo, pad);
   if ((C0 + C1) != L.CGp * 4) return fail(c, "layer %s: source channels %d+%d != packed %d", d.name, C0, C1, L.CGp * 4);
   // Low-latency mode (SE_FLAG_LOW_LATENCY, one or two images): the Winograd kernels' 64/128-tile workgroups would
   // occupy 16-32 of the 256 CUs, so every gated conv takes the direct kernel in its small-grid shape instead
@@ -562,8 +696,14 @@ struct Plan {
     return p;
   }
   Act alloc(int H, int W, int C) {
-    Act a; a.H = H; a.W = W; a.C = C;
-    a.p = alloc_raw((size_t)B * H * W * C);
+    Act a; a.H = H; a.W = W;
+    if (c->bf16) {       // bf16 activations: whole 8-channel granules per pixel (12 -> 16, 4 / 5 -> 8), two per float slot
+      a.C = (C + 7) & ~7;
+      a.p = alloc_raw(((size_t)B * H * W * a.C + 1) / 2);
+    } else {
+      a.C = C;
+      a.p = alloc_raw((size_t)B * H * W * C);
+    }
     return a;
   }
   void release(const float* p) {          // to whichever arena the block came from
@@ -655,7 +795,8 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
     if (!L.packed) return P.rc = fail(c, "layer %s: weights not loaded", name);
     SmallConvParams sp;
     memset(&sp, 0, sizeof sp);
-    sp.x = in.p; sp.w = L.d_w; sp.b = L.d_b; sp.B = P.B; sp.H = in.H; sp.W = in.W; sp.cout = L.def.cout;
+    sp.x = in.p; sp.w = c->bf16 ? L.d_w16 : L.d_w; sp.b = L.d_b; sp.B = P.B; sp.H = in.H; sp.W = in.W; sp.cout = L.def.cout;
+    sp.bf16 = c->bf16 ? 1 : 0;
     sp.mode = mode; sp.out_nchw = out_nchw; sp.hard = hard; sp.img = img; sp.mask = mask; sp.xnow = xnow;
     sp.composed = composed; sp.no_mask_coarse = no_mask_coarse;
     if (packed_bs) {      // SE_FLAG_PACKED_OUT: soft mask and composite live in one (B,4,H,W) buffer
@@ -677,7 +818,7 @@ int plan_netM(se_ctx* c, const float* image, const float* sketch, float* mask_ou
   Plan P(c, c->M, B);
   Act in = P.alloc(H, W, 4);
   if (P.rc) return P.rc;
-  if (!c->dry) HIPCHK(c, launch_pack_m(image, sketch, in.p, B, H, W, c->st));
+  if (!c->dry) HIPCHK(c, c->bf16 ? launch_pack_m16(image, sketch, in.p, B, H, W, c->st) : launch_pack_m(image, sketch, in.p, B, H, W, c->st));
   Act x9;
   const bool want_img = maskim_out != nullptr;
   Act x10 = encoder(P, "conv", in, want_img ? &x9 : nullptr);
@@ -706,17 +847,20 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   P.ar = &c->arena;
   if (P.rc) return P.rc;
   if (!c->dry)
-    HIPCHK(c, launch_pack_g(x, x2, mask, mask2, guide, cin.p, sin.p, B, H, W, (flags & SE_FLAG_NO_MASK_CC) ? 1 : 0,
-                            joint, c->st));
+    HIPCHK(c, (c->bf16 ? launch_pack_g16 : launch_pack_g)(x, x2, mask, mask2, guide, cin.p, sin.p, B, H, W,
+                                                          (flags & SE_FLAG_NO_MASK_CC) ? 1 : 0, joint, c->st));
   // ---- style branch :149-163 -> (B,96) pooled vector, consumed by conv11 as a second (spatially constant) source
   if (P.side_begin()) return 1;
   Act xs = encoder(P, "wconv", sin, nullptr, joint ? &c->wconv1_j4 : nullptr);
-  Act part = P.alloc(1, COLREDUCE_SPLITS, 96), vec = P.alloc(1, 1, 96);
+  // (in bf16 mode `part` / `vec32` hold fp32 values in twice the room they need; `vec` is the bf16 vector conv11 reads)
+  Act part = P.alloc(1, COLREDUCE_SPLITS, 192), vec32 = P.alloc(1, 1, 192), vec = P.alloc(1, 1, 96);
   if (P.rc) return P.rc;
   if (!c->dry)
-    HIPCHK(c, launch_colreduce(xs.p, part.p, vec.p, B, xs.H * xs.W, 96, (flags & SE_FLAG_POOL_MAX) ? 0 : 1, c->st));
+    HIPCHK(c, launch_colreduce(xs.p, part.p, c->bf16 ? vec32.p : vec.p, B, xs.H * xs.W, 96, (flags & SE_FLAG_POOL_MAX) ? 0 : 1,
+                               c->st, c->bf16 ? 1 : 0, c->bf16 ? vec.p : nullptr));
   P.free(xs);
   P.free(part);
+  P.free(vec32);
   if (P.side_end()) return 1;
   // ---- coarse branch :138-147
   Act xc = encoder(P, "conv", cin, nullptr);
@@ -770,30 +914,34 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
 int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, float* similar_nchw) {
   const int h = x.H, w = x.W, B = P.B;
   const int hs = (h - 4) / 2 + 1, ws = (w - 4) / 2 + 1, L = hs * ws, Lp = (L + 31) & ~31;
-  const int hc = h / 2, wc = w / 2, R = hc * wc, Rp = (R + 31) & ~31;
-  const bool v2 = attention_v2_enabled();
+  const bool bf = c->bf16;
+  const bool v2 = attention_v2_enabled() || bf;       // the bf16 path exists in the space-to-depth form only
+  const int hc = h / 2, wc = w / 2, R = hc * wc, Rp = bf ? (R + 63) & ~63 : (R + 31) & ~31;
   if (v2 && (double)R * Rp * 4.0 >= 2147483648.0) return P.rc = fail(c, "attention: %dx%d feature map too large", h, w);
-  Act part = P.alloc(1, COLREDUCE_SPLITS, 96), rn = P.alloc(1, 1, 96), xn = P.alloc(h, w, 96);
+  // fp32 scratch is sized in floats whatever the activation type
+  float* part = P.alloc_raw((size_t)B * COLREDUCE_SPLITS * 96);
+  float* rn = P.alloc_raw((size_t)B * 96);
+  float* xn = P.alloc_raw(bf ? ((size_t)B * h * w * 96 + 1) / 2 : (size_t)B * h * w * 96);
   float *valid = nullptr, *S = nullptr, *S2 = nullptr, *xT = nullptr;
   if (v2) {
-    valid = P.ar->alloc((size_t)B * Rp);
-    xT = P.ar->alloc((size_t)B * 4 * 96 * Rp);
-    S = P.ar->alloc((size_t)B * R * Rp);       // E, then P~
-    S2 = P.ar->alloc((size_t)B * R * Rp);      // P
+    valid = P.alloc_raw((size_t)B * Rp);
+    xT = P.alloc_raw(bf ? (size_t)B * 4 * 96 * Rp / 2 : (size_t)B * 4 * 96 * Rp);
+    S = P.alloc_raw((size_t)B * R * Rp);       // E (fp32), then P~ (fp32, or bf16 in its front half)
+    S2 = P.alloc_raw((size_t)B * R * Rp);      // P
   } else {
-    valid = P.ar->alloc((size_t)B * Lp);
-    S = P.ar->alloc((size_t)B * L * Lp);
+    valid = P.alloc_raw((size_t)B * Lp);
+    S = P.alloc_raw((size_t)B * L * Lp);
   }
-  if (!part.p || !rn.p || !xn.p || !valid || !S || (v2 && (!S2 || !xT))) return P.rc = fail(c, "workspace too small (attention)");
+  if (P.rc) return P.rc;
   if (!c->dry) {
-    HIPCHK(c, launch_colreduce(x.p, part.p, rn.p, B, h * w, 96, 2, c->st));
+    HIPCHK(c, launch_colreduce(x.p, part, rn, B, h * w, 96, 2, c->st, bf ? 1 : 0));
     AttParams a;
     memset(&a, 0, sizeof a);
-    a.x = x.p; a.rn = rn.p; a.xn = xn.p; a.hard = mask_full; a.out = out.p;
+    a.x = x.p; a.rn = rn; a.xn = xn; a.hard = mask_full; a.out = out.p;
     a.B = B; a.h = h; a.w = w; a.hs = hs; a.ws = ws; a.L = L; a.Lp = Lp;
     a.scale = 10.f; a.th = 0.1f;                        // editline_g.py:35-38
     if (v2) {
-      a.hc = hc; a.wc = wc; a.R = R; a.Rp = Rp;
+      a.hc = hc; a.wc = wc; a.R = R; a.Rp = Rp; a.bf16 = bf ? 1 : 0;
       a.validR = valid; a.xT = xT; a.E = S; a.P = S2; a.similar = similar_nchw;
       HIPCHK(c, launch_attention(a, c->st));
     } else {
@@ -806,7 +954,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
     }
   }
   P.release(S2); P.release(S); P.release(xT); P.release(valid);
-  P.free(xn); P.free(rn); P.free(part);
+  P.release(xn); P.release(rn); P.release(part);
   return 0;
 }
 
@@ -818,13 +966,15 @@ int check_dims(se_ctx* c, int B, int H, int W) {
 // Arena peaks of a forward, from a dry run of the very plan that will be launched (nothing is enqueued): main-branch
 // arena and, in low-latency mode, the side-branch arena.  which: 1 netM, 2 netG, 3 netM then netG (se_inference).
 se_ctx::Peaks plan_peaks(se_ctx* c, int which, int B, int H, int W, int flags, bool want_maskim) {
-  const std::vector<long long> key = {which, B, H, W, flags & (SE_FLAG_USE_CAM | SE_FLAG_JOINT_TRAIN_INP | SE_FLAG_LOW_LATENCY),
+  const std::vector<long long> key = {which, B, H, W,
+                                      flags & (SE_FLAG_USE_CAM | SE_FLAG_JOINT_TRAIN_INP | SE_FLAG_LOW_LATENCY | SE_FLAG_BF16),
                                       want_maskim ? 1 : 0, attention_v2_enabled() ? 1 : 0};
   auto it = c->peaks.find(key);
   if (it != c->peaks.end()) return it->second;
-  const bool dry0 = c->dry, ll0 = c->low_latency;
+  const bool dry0 = c->dry, ll0 = c->low_latency, bf0 = c->bf16;
   c->dry = true;
   c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
+  c->bf16 = (flags & SE_FLAG_BF16) != 0;
   float dummy;      // non-null marker for optional outputs
   se_ctx::Peaks pk{0, 0};
   if (which & 1) {
@@ -838,7 +988,7 @@ se_ctx::Peaks plan_peaks(se_ctx* c, int which, int B, int H, int W, int flags, b
     if (c->arena.peak > pk.main) pk.main = c->arena.peak;
     if (c->arena2.peak > pk.side) pk.side = c->arena2.peak;
   }
-  c->dry = dry0; c->low_latency = ll0;
+  c->dry = dry0; c->low_latency = ll0; c->bf16 = bf0;
   c->peaks[key] = pk;
   return pk;
 }
@@ -857,6 +1007,7 @@ void begin_call(se_ctx* c, void* stream, int flags) {
   c->st = c->st_main = (hipStream_t)stream;
   c->dry = false;
   c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
+  c->bf16 = (flags & SE_FLAG_BF16) != 0;
   set_profiler(&c->prof);
 }
 
@@ -910,9 +1061,11 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_b) (void)hipFree(kv.second.d_b);
       if (kv.second.d_u) (void)hipFree(kv.second.d_u);
       if (kv.second.d_ub) (void)hipFree(kv.second.d_ub);
+      if (kv.second.d_w16) (void)hipFree(kv.second.d_w16);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
+  if (c->wconv1_j4.d_w16) (void)hipFree(c->wconv1_j4.d_w16);
   if (c->zeros) (void)hipFree(c->zeros);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
   drop_graphs(c);
@@ -989,16 +1142,22 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
   return peak + (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask plane used by se_inference
 }
 
-int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
-                    float* maskim_out, void* ws, size_t ws_bytes, int B, int H, int W) {
+int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
+                       float* maskim_out, void* ws, size_t ws_bytes, int B, int H, int W, int exec_flags) {
   if (!c) return 1;
   std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
-  if (carve(c, plan_peaks(c, 1, B, H, W, 0, maskim_out != nullptr), ws, ws_bytes, 0)) return 1;
-  begin_call(c, stream, 0);
+  exec_flags &= SE_FLAG_LOW_LATENCY | SE_FLAG_BF16;
+  if (carve(c, plan_peaks(c, 1, B, H, W, exec_flags, maskim_out != nullptr), ws, ws_bytes, 0)) return 1;
+  begin_call(c, stream, exec_flags);
   return plan_netM(c, image, sketch, mask_out, nullptr, maskim_out, B, H, W);
+}
+
+int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
+                    float* maskim_out, void* ws, size_t ws_bytes, int B, int H, int W) {
+  return se_netM_forward_ex(c, stream, image, sketch, mask_out, maskim_out, ws, ws_bytes, B, H, W, 0);
 }
 
 int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, const float* mask, const float* mask2,
@@ -1067,6 +1226,7 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
                              ws_bytes, B, H, W, flags);
   }
   if (!ge->exec) {
+    if (!stream) return fail(c, "SE_FLAG_GRAPH needs a non-default stream (capture is not permitted on the legacy stream)");
     HIPCHK(c, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out,
                                      fine_out, ws, ws_bytes, B, H, W, flags);
@@ -1167,7 +1327,8 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (!c || !x || !w_host || !b_host || !y) return 1;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  begin_call(c, stream, exec_flags & SE_FLAG_LOW_LATENCY);
+  begin_call(c, stream, exec_flags & (SE_FLAG_LOW_LATENCY | SE_FLAG_BF16));
+  const bool bf = c->bf16;
   if (!x1) Cin1 = 0;
   if (x1 && ((Cin % 4) || (Cin1 % 4))) return fail(c, "two-source conv: channel counts must be multiples of 4");
   Layer L;
@@ -1176,17 +1337,19 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   L.def = LayerDef{nm, CinT, Cout, k, stride, rate, act, upsample};
   L.w.assign(w_host, w_host + (size_t)Cout * CinT * k * k);
   L.b.assign(b_host, b_host + Cout);
-  const int Cp = (Cin + 3) & ~3;
+  if (bf && x1 && ((Cin % 8) || (Cin1 % 8))) return fail(c, "two-source bf16 conv: channel counts must be multiples of 8");
+  const int Cp = bf ? (Cin + 7) & ~7 : (Cin + 3) & ~3;
   float *xin = nullptr, *x1in = nullptr, *yout = nullptr;
   int rc = 0;
   HIPCHK(c, hipMalloc(&xin, (size_t)B * H * W * Cp * 4));
-  rc = launch_nchw_to_nhwc(x, xin, B, Cin, Cp, H, W, c->st) != hipSuccess;
+  rc = (bf ? launch_nchw_to_nhwc16 : launch_nchw_to_nhwc)(x, xin, B, Cin, Cp, H, W, c->st) != hipSuccess;
   if (!rc && x1) {
     // second source of the virtual concat (editline_g.py:166-167,211): a tensor (B,Cin1,H,W) or a per-image vector (B,Cin1)
     const size_t n1 = x1_is_vector ? (size_t)B * Cin1 : (size_t)B * H * W * Cin1;
     HIPCHK(c, hipMalloc(&x1in, n1 * 4));
-    if (x1_is_vector) rc = hipMemcpyAsync(x1in, x1, n1 * 4, hipMemcpyDeviceToDevice, c->st) != hipSuccess;
-    else rc = launch_nchw_to_nhwc(x1, x1in, B, Cin1, Cin1, H, W, c->st) != hipSuccess;
+    if (x1_is_vector && !bf) rc = hipMemcpyAsync(x1in, x1, n1 * 4, hipMemcpyDeviceToDevice, c->st) != hipSuccess;
+    else if (x1_is_vector) rc = launch_nchw_to_nhwc16(x1, x1in, B, Cin1, Cin1, 1, 1, c->st) != hipSuccess;
+    else rc = (bf ? launch_nchw_to_nhwc16 : launch_nchw_to_nhwc)(x1, x1in, B, Cin1, Cin1, H, W, c->st) != hipSuccess;
   }
   const bool raw = (act == ACT_NONE) || Cout == 3;    // utils.py:27
   if (!rc && raw) {
@@ -1195,19 +1358,22 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
     if (!rc) {
       SmallConvParams sp;
       memset(&sp, 0, sizeof sp);
-      sp.x = xin; sp.w = L.d_w; sp.b = L.d_b; sp.B = B; sp.H = H; sp.W = W; sp.cout = Cout; sp.mode = 4;
+      sp.x = xin; sp.w = bf ? L.d_w16 : L.d_w; sp.b = L.d_b; sp.B = B; sp.H = H; sp.W = W; sp.cout = Cout; sp.mode = 4;
+      sp.bf16 = bf ? 1 : 0;
       sp.out_nchw = y;
       rc = launch_small_conv(sp, c->st) != hipSuccess;
     }
   } else if (!rc) {
     if (Cout % 8) rc = fail(c, "gated conv needs Cout %% 8 == 0");
     if (!rc) rc = pack_layer(c, L, identity_map(CinT));
+    if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
     if (!rc) {
       int Ho, Wo;
       c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
-      HIPCHK(c, hipMalloc(&yout, (size_t)B * Ho * Wo * (Cout / 2) * 4));
+      const int Gs = bf ? (Cout / 2 + 7) & ~7 : Cout / 2;
+      HIPCHK(c, hipMalloc(&yout, (size_t)B * Ho * Wo * Gs * 4));
       rc = run_gconv(c, L, xin, Cp, x1in, Cin1, x1_is_vector, yout, B, H, W, nullptr, nullptr);
-      if (!rc) rc = launch_nhwc_to_nchw(yout, y, B, Cout / 2, Cout / 2, Ho, Wo, c->st) != hipSuccess;
+      if (!rc) rc = (bf ? launch_nhwc16_to_nchw : launch_nhwc_to_nchw)(yout, y, B, Cout / 2, Gs, Ho, Wo, c->st) != hipSuccess;
     }
   }
   (void)hipStreamSynchronize(c->st);
@@ -1218,6 +1384,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_b) (void)hipFree(L.d_b);
   if (L.d_u) (void)hipFree(L.d_u);
   if (L.d_ub) (void)hipFree(L.d_ub);
+  if (L.d_w16) (void)hipFree(L.d_w16);
   return rc;
 }
 
@@ -1227,14 +1394,15 @@ int se_gated_conv2d(se_ctx* c, void* stream, const float* x, const float* w_host
                             upsample, 0);
 }
 
-int se_attention(se_ctx* c, void* stream, const float* x, const float* mask_full, float* out, float* similar_out, int B,
-                 int h, int w) {
+int se_attention_ex(se_ctx* c, void* stream, const float* x, const float* mask_full, float* out, float* similar_out, int B,
+                    int h, int w, int exec_flags) {
   if (!c || !x || !mask_full || !out) return 1;
-  if (h < 4 || w < 4 || (h % 2) || (w % 2)) return fail(c, "attention: h, w must be even and >= 4");
   std::lock_guard<std::mutex> lk(c->mu);
+  if (h < 4 || w < 4 || (h % 2) || (w % 2)) return fail(c, "attention: h, w must be even and >= 4");
   HIPCHK(c, hipSetDevice(c->device));
-  begin_call(c, stream, 0);
-  const int R = (h / 2) * (w / 2), Rp = (R + 31) & ~31;
+  begin_call(c, stream, exec_flags & SE_FLAG_BF16);
+  const bool bf = c->bf16;
+  const int R = (h / 2) * (w / 2), Rp = (R + 63) & ~63;
   const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (1 + 4 * 96) + 64 * 96 * B) * 4 + (1 << 16);
   char* ws = nullptr;
   HIPCHK(c, hipMalloc(&ws, bytes));
@@ -1243,12 +1411,17 @@ int se_attention(se_ctx* c, void* stream, const float* x, const float* mask_full
   Plan P(c, c->G, B);
   Act xin = P.alloc(h, w, 96), o = P.alloc(h, w, 96);
   int rc = P.rc;
-  if (!rc) rc = launch_nchw_to_nhwc(x, xin.p, B, 96, 96, h, w, c->st) != hipSuccess;
+  if (!rc) rc = (bf ? launch_nchw_to_nhwc16 : launch_nchw_to_nhwc)(x, xin.p, B, 96, 96, h, w, c->st) != hipSuccess;
   if (!rc) rc = run_attention(c, P, xin, mask_full, o, similar_out);
-  if (!rc) rc = launch_nhwc_to_nchw(o.p, out, B, 96, 96, h, w, c->st) != hipSuccess;
+  if (!rc) rc = (bf ? launch_nhwc16_to_nchw : launch_nhwc_to_nchw)(o.p, out, B, 96, 96, h, w, c->st) != hipSuccess;
   (void)hipStreamSynchronize(c->st);
   (void)hipFree(ws);
   return rc;
+}
+
+int se_attention(se_ctx* c, void* stream, const float* x, const float* mask_full, float* out, float* similar_out, int B,
+                 int h, int w) {
+  return se_attention_ex(c, stream, x, mask_full, out, similar_out, B, h, w, 0);
 }
 
 }  // extern "C"

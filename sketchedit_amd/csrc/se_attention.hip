@@ -334,16 +334,29 @@ static hipError_t launch_attention_v1(const AttParams& p, hipStream_t st) {
 // Summation order differs from the reference's conv (fp32 rounding only): measured <= 2e-6 on `similar`.
 // =====================================================================================================================
 
+// BF16 (all att2 kernels): x, xn, xT, P~ and out are bf16 (8-channel granules, 64-key chunks); E, the softmax and P stay fp32.
+template <bool BF16>
 __global__ void att2_prep_kernel(const AttParams p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long nx = (long)p.B * p.h * p.w * 24;    // granules
+  const long nx = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);    // granules
   if (idx < nx) {
-    const int cg = idx % 24;
-    const long pix = idx / 24;
-    const int b = pix / (p.h * p.w);
-    const f32x4 v = *(const f32x4*)(p.x + idx * 4);
-    const f32x4 r = *(const f32x4*)(p.rn + b * 96 + cg * 4);
-    *(f32x4*)(p.xn + idx * 4) = v * r;                        // splitcam.py:40
+    if (BF16) {
+      const int cg = idx % 12;
+      const long pix = idx / 12;
+      const int b = pix / (p.h * p.w);
+      const uint4 v = *(const uint4*)((const char*)p.x + idx * 16);
+      const f32x4 r0 = *(const f32x4*)(p.rn + b * 96 + cg * 8), r1 = *(const f32x4*)(p.rn + b * 96 + cg * 8 + 4);
+      *(uint4*)((char*)p.xn + idx * 16) =
+          make_uint4(pack_bf16x2(bf16_lo(v.x) * r0[0], bf16_hi(v.x) * r0[1]), pack_bf16x2(bf16_lo(v.y) * r0[2], bf16_hi(v.y) * r0[3]),
+                     pack_bf16x2(bf16_lo(v.z) * r1[0], bf16_hi(v.z) * r1[1]), pack_bf16x2(bf16_lo(v.w) * r1[2], bf16_hi(v.w) * r1[3]));
+    } else {
+      const int cg = idx % 24;
+      const long pix = idx / 24;
+      const int b = pix / (p.h * p.w);
+      const f32x4 v = *(const f32x4*)(p.x + idx * 4);
+      const f32x4 r = *(const f32x4*)(p.rn + b * 96 + cg * 4);
+      *(f32x4*)(p.xn + idx * 4) = v * r;                        // splitcam.py:40
+    }
   }
   if (idx < (long)p.B * p.Rp) {
     const int b = idx / p.Rp, s = idx - (long)b * p.Rp;
@@ -364,6 +377,7 @@ __global__ void att2_prep_kernel(const AttParams p) {
 }
 
 // xT[b][cls][c][s] = x[b][2sy+py][2sx+px][c] (raw values, splitcam.py:138-143), zero for s >= R.  Block = 32 keys of one class.
+template <bool BF16>
 __global__ __launch_bounds__(256) void att2_transpose_kernel(const AttParams p) {
   __shared__ float t[32][97];
   const int s0 = blockIdx.x * 32, cls = blockIdx.y, b = blockIdx.z, py = cls >> 1, px = cls & 1;
@@ -372,21 +386,25 @@ __global__ __launch_bounds__(256) void att2_transpose_kernel(const AttParams p) 
     float v = 0.f;
     if (s < p.R) {
       const int sy = s / p.wc, sx = s - sy * p.wc;
-      v = p.x[((size_t)(b * p.h + 2 * sy + py) * p.w + 2 * sx + px) * 96 + c];
+      const size_t at = ((size_t)(b * p.h + 2 * sy + py) * p.w + 2 * sx + px) * 96 + c;
+      v = BF16 ? __uint_as_float((unsigned)((const unsigned short*)p.x)[at] << 16) : p.x[at];
     }
     t[sl][c] = v;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 96 * 32; e += 256) {
     const int c = e >> 5, sl = e & 31;
-    p.xT[(((size_t)b * 4 + cls) * 96 + c) * p.Rp + s0 + sl] = t[sl][c];
+    const size_t at = (((size_t)b * 4 + cls) * 96 + c) * p.Rp + s0 + sl;
+    if (BF16) ((unsigned short*)p.xT)[at] = (unsigned short)(__float_as_uint(t[sl][c]) >> 16);      // exact: t holds a bf16 value
+    else p.xT[at] = t[sl][c];
   }
 }
 
 // E[b][r][s] = <2x2x96 block of x at class-grid position r, 2x2x96 block of xn at s>; rows of the A tile = keys s,
 // MFMA columns = queries r; written query-major so that the softmax axis is contiguous.
-template <int NT, int PT>
+template <int NT, int PT, bool BF16>
 __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
+  constexpr int PXB = BF16 ? 192 : 384;        // bytes per pixel (96 channels)
   constexpr int PIX = PT * 64, NP = NT * 16;
   constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
   constexpr int NX = PT * 2, NW = (NT * 2 + 3) / 4;
@@ -402,10 +420,10 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   auto origin = [&](int i) -> unsigned {
     if (i >= p.R) return 0x80000000u;
     const int ry = i / p.wc, rx = i - ry * p.wc;
-    return (unsigned)(((2 * ry) * p.w + 2 * rx) * 384);
+    return (unsigned)(((2 * ry) * p.w + 2 * rx) * PXB);
   };
-  const se_i32x4 rs_q = make_rsrc(p.x + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
-  const se_i32x4 rs_k = make_rsrc(p.xn + (size_t)b * p.h * p.w * 96, (unsigned)p.h * p.w * 96u * 4u);
+  const se_i32x4 rs_q = make_rsrc((const char*)p.x + (size_t)b * p.h * p.w * PXB, (unsigned)p.h * p.w * (unsigned)PXB);
+  const se_i32x4 rs_k = make_rsrc((const char*)p.xn + (size_t)b * p.h * p.w * PXB, (unsigned)p.h * p.w * (unsigned)PXB);
   unsigned qo[NX], ko[NW];
 #pragma unroll
   for (int i = 0; i < NX; ++i) qo[i] = origin(q0 + (i * 4 + w) * 8 + (lane >> 3));
@@ -418,9 +436,10 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
 
   auto stage = [&](int ch, int buf) {
-    const int gi = ch * 8 + s_log;                 // granule of the 4 pixels x 24 channel groups
-    const int tap = (gi * 2731) >> 16, cg = gi - tap * 24;      // gi / 24 for gi < 4096
-    const unsigned doff = (unsigned)((__mul24(tap >> 1, p.w) + (tap & 1)) * 384 + cg * 16);
+    const int gi = ch * 8 + s_log;                 // granule of the 4 pixels x 24 (bf16: 12) channel groups
+    constexpr int GPP = BF16 ? 12 : 24;            // granules per pixel
+    const int tap = (gi * (BF16 ? 5462 : 2731)) >> 16, cg = gi - tap * GPP;      // gi / GPP on the range used
+    const unsigned doff = (unsigned)((__mul24(tap >> 1, p.w) + (tap & 1)) * PXB + cg * 16);
     const unsigned xdst = lds_x + buf * XBYTES, wdst = lds_w + buf * WBYTES;
 #pragma unroll
     for (int i = 0; i < NX; ++i) bufdma16(qo[i] + doff, rs_q, xdst + (i * 4 + w) * 1024);
@@ -436,14 +455,15 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int NCH = 12;   // 4 pixels * 96 ch / 32
+  constexpr int NCH = BF16 ? 6 : 12;   // 4 pixels * 96 ch / (64 | 32)
   stage(0, 0);
   dma_wait_all();
   __syncthreads();
   for (int ch = 0; ch < NCH; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < NCH) stage(ch + 1, buf ^ 1);
-    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    if (BF16) mfma_chunk16<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    else mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
     dma_wait_all();
     __syncthreads();
   }
@@ -505,8 +525,56 @@ __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
   }
 }
 
+// The same with the whole row in registers (R <= 64 * NV): E is read once, P written once.
+template <int NV>
+__global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= (long)p.B * p.L) return;
+  const int b = qi / p.L, i = qi - (long)b * p.L;
+  const int iy = i / p.ws, ix = i - iy * p.ws;
+  const int r0 = iy * p.wc + ix;
+  const float* E0 = p.E + ((size_t)b * p.R + r0) * p.Rp;
+  const float* E1 = E0 + p.Rp;
+  const float* E2 = E0 + (size_t)p.wc * p.Rp;
+  const float* E3 = E2 + p.Rp;
+  const float* vr = p.validR + (size_t)b * p.Rp;
+  float* P = p.P + ((size_t)b * p.R + r0) * p.Rp;
+  const int o2 = p.wc, o3 = p.wc + 1;
+  float v[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int s = lane + 64 * k;
+    float sc = -INFINITY;                     // not a key: exp() below gives 0
+    if (s < p.R) {
+      const float vv = vr[s];
+      if (vv >= 0.f) sc = (E0[s] + E1[s + 1] + E2[s + o2] + E3[s + o3]) * vv * p.scale;
+    }
+    v[k] = sc;
+    m = fmaxf(m, sc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] = expf(v[k] - m);
+    sum += v[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int s = lane + 64 * k;
+    if (s < p.Rp) P[s] = v[k] * inv;
+  }
+}
+
 // One wave per class-grid row r: P~[r][s] = sum over the <= 4 patches (query r-d, key s-d) that pair pixel r with pixel s.
 // P is zero at non-key columns, so only s - d < 0 needs a test on the key side.  Overwrites E.
+template <bool BF16>
 __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
   const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -514,7 +582,8 @@ __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
   const int b = qi / p.R, r = qi - (long)b * p.R;
   const int ry = r / p.wc, rx = r - ry * p.wc;
   const float* Pb = p.P + (size_t)b * p.R * p.Rp;
-  float* out = p.E + ((size_t)b * p.R + r) * p.Rp;
+  // row r of P~: fp32, or bf16 packed into the front half of the E buffer (rounded once, here)
+  char* out = (char*)p.E + ((size_t)b * p.R + r) * p.Rp * (BF16 ? 2 : 4);
   const float* src[4];
   int off[4];
 #pragma unroll
@@ -524,21 +593,28 @@ __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
     src[d] = ok ? Pb + (size_t)(qy * p.wc + qx) * p.Rp : nullptr;
     off[d] = dy * p.wc + dx;
   }
-  for (int s = lane; s < p.Rp; s += 64) {
-    float a = 0.f;
-    if (s < p.R) {
+#pragma unroll 4
+  for (int s0 = 2 * lane; s0 < p.Rp; s0 += 128) {        // Rp is even: two columns per lane
+    float a[2] = {0.f, 0.f};
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
-        if (src[d] && s >= off[d]) a += src[d][s - off[d]];
+    for (int u = 0; u < 2; ++u) {
+      const int s = s0 + u;
+      if (s < p.R) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          if (src[d] && s >= off[d]) a[u] += src[d][s - off[d]];
+      }
     }
-    out[s] = a;
+    if (BF16) *(unsigned*)(out + s0 * 2) = pack_bf16x2(a[0], a[1]);
+    else *(float2*)(out + s0 * 4) = make_float2(a[0], a[1]);
   }
 }
 
 // out[b, 2r + cls, c] = sum_s P~[r][s] * xT[cls][c][s]: A tile = 96 channel rows x 32 keys, MFMA columns = class-grid pixels
-template <int PT>
+template <int PT, bool BF16>
 __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
   constexpr int NT = 6, PIX = PT * 64, NP = 96;
+  constexpr int ES = BF16 ? 2 : 4;
   constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
   constexpr int NX = PT * 2, NW = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -550,20 +626,20 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
   const int b = blockIdx.z, cls = blockIdx.y, py = cls >> 1, px = cls & 1;
   const int t0 = blockIdx.x * PIX;
   const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
-  const se_i32x4 rs_P = make_rsrc(p.E + (size_t)b * p.R * p.Rp, (unsigned)p.R * p.Rp * 4u);
-  const se_i32x4 rs_V = make_rsrc(p.xT + ((size_t)b * 4 + cls) * 96 * p.Rp, 96u * p.Rp * 4u);
+  const se_i32x4 rs_P = make_rsrc((const char*)p.E + (size_t)b * p.R * p.Rp * ES, (unsigned)p.R * p.Rp * (unsigned)ES);
+  const se_i32x4 rs_V = make_rsrc((const char*)p.xT + ((size_t)b * 4 + cls) * 96 * p.Rp * ES, 96u * p.Rp * (unsigned)ES);
   unsigned xo[NX], wo[NW];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int r = t0 + (i * 4 + w) * 8 + (lane >> 3);
-    xo[i] = r < p.R ? (unsigned)(r * p.Rp + s_log * 4) * 4u : 0x80000000u;
+    xo[i] = r < p.R ? (unsigned)(r * p.Rp) * (unsigned)ES + s_log * 16u : 0x80000000u;
   }
 #pragma unroll
-  for (int j = 0; j < NW; ++j) wo[j] = (unsigned)(((j * 4 + w) * 8 + (lane >> 3)) * p.Rp + s_log * 4) * 4u;
+  for (int j = 0; j < NW; ++j) wo[j] = (unsigned)(((j * 4 + w) * 8 + (lane >> 3)) * p.Rp) * (unsigned)ES + s_log * 16u;
   int off0, off1;
   frag_offsets(lane, off0, off1);
   const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
-  const int nch = p.Rp >> 5;
+  const int nch = BF16 ? p.Rp >> 6 : p.Rp >> 5;
 
   auto stage = [&](int ch, int buf) {
     const unsigned delta = (unsigned)ch * 128u;
@@ -585,7 +661,8 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nch) stage(ch + 1, buf ^ 1);
-    mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    if (BF16) mfma_chunk16<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+    else mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
     dma_wait_all();
     __syncthreads();
   }
@@ -595,9 +672,13 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
     const int i = t0 + (w * PT + pt) * 16 + (lane & 15);
     if (i >= p.R) continue;
     const int yy = i / p.wc, xx = i - yy * p.wc;
-    float* o = p.out + ((long)(b * p.h + 2 * yy + py) * p.w + 2 * xx + px) * 96;
+    char* o = (char*)p.out + ((long)(b * p.h + 2 * yy + py) * p.w + 2 * xx + px) * 96 * ES;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) *(f32x4*)(o + nt * 16 + q * 4) = acc[nt][pt];
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 a = acc[nt][pt];
+      if (BF16) *(uint2*)(o + (nt * 16 + q * 4) * 2) = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+      else *(f32x4*)(o + (nt * 16 + q * 4) * 4) = a;
+    }
   }
 }
 
@@ -612,28 +693,32 @@ __global__ void att2_similar_kernel(const AttParams p) {
   p.similar[idx] = p.P[((size_t)b * p.R + r) * p.Rp + s];
 }
 
-static hipError_t launch_attention_v2(const AttParams& p, hipStream_t st) {
+template <bool BF16>
+static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
   {
-    const long n = (long)p.B * p.h * p.w * 24;
+    const long n = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);
     ProfScope ps_(st, PL_ATT_PREP);
-    hipLaunchKernelGGL(att2_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(att2_transpose_kernel, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(att2_prep_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(att2_transpose_kernel<BF16>, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);
   }
   {
     constexpr int NT = 4, PT = 4;
     constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
-    hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT>, LDS);
+    hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
     if (e != hipSuccess) return e;
     dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
-    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 4.0 * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
+    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * (double)p.R * p.R * 384.0);
     ProfScope ps_(st, PL_ATT_SCORE);
-    hipLaunchKernelGGL((att2_pair_kernel<NT, PT>), grid, dim3(256), LDS, st, p);
+    hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
   }
   {
     const long rows = (long)p.B * p.L;
     ProfScope ps_(st, PL_ATT_SOFTMAX);
-    hipLaunchKernelGGL(att2_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (p.Rp <= 64 * 16) hipLaunchKernelGGL(att2_softmax_reg_kernel<16>, grid, dim3(256), 0, st, p);
+    else if (p.Rp <= 64 * 64) hipLaunchKernelGGL(att2_softmax_reg_kernel<64>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(att2_softmax_kernel, grid, dim3(256), 0, st, p);
   }
   if (p.similar) {
     const long n = (long)p.B * p.L * p.L;
@@ -643,20 +728,23 @@ static hipError_t launch_attention_v2(const AttParams& p, hipStream_t st) {
   {
     const long rows = (long)p.B * p.R;
     ProfScope ps_(st, PL_ATT_BOXSUM);
-    hipLaunchKernelGGL(att2_boxsum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   }
   {
     constexpr int PT = 4;
     constexpr int LDS = 2 * PT * 64 * 128 + 2 * 96 * 128;
-    hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT>, LDS);
+    hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, BF16>, LDS);
     if (e != hipSuccess) return e;
     dim3 grid((p.R + PT * 64 - 1) / (PT * 64), 4, p.B);
-    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, 4.0 * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
+    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * 4.0 * (double)p.R * p.Rp * 96.0);
     ProfScope ps_(st, PL_ATT_PV);
-    hipLaunchKernelGGL((att2_pv_kernel<PT>), grid, dim3(256), LDS, st, p);
+    hipLaunchKernelGGL((att2_pv_kernel<PT, BF16>), grid, dim3(256), LDS, st, p);
   }
   return hipGetLastError();
+}
+static hipError_t launch_attention_v2(const AttParams& p, hipStream_t st) {
+  return p.bf16 ? launch_attention_v2_t<true>(p, st) : launch_attention_v2_t<false>(p, st);
 }
 
 // SE_ATT_V1=1 selects the patch form (materialised L x L scores, K = 1536 / 4L) for A/B measurements

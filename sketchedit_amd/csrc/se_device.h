@@ -150,6 +150,46 @@ DEVFN void mfma_chunk(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const c
   }
 }
 
+// ---- bf16 storage (BASELINE config 5: bf16 operands, fp32 accumulate) ------------------------------------------------
+// Activations and weights are stored as bf16; a 16-byte granule holds 8 channels, a 128-byte LDS row 64 k-values, and
+// the tile / swizzle / fragment-offset geometry is the fp32 one: lane l of v_mfma_f32_16x16x32_bf16 supplies the 8
+// consecutive k-values of k-group (l >> 4) for row / column (l & 15), i.e. exactly one 16-byte slot, and the C/D layout
+// is the same as for the fp32 instruction.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// two fp32 -> one dword of two bf16 (round to nearest even), lo in bits 0-15
+DEVFN unsigned pack_bf16x2(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+DEVFN float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+DEVFN float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// One 64-k chunk of bf16 operands: same tile addressing as mfma_chunk, one MFMA per (k-half, channel tile, pixel tile)
+template <int NT, int PT, typename Hook = NoHook>
+DEVFN void mfma_chunk16(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const char* __restrict__ Xt, int off0,
+                        int off1, Hook hook = Hook()) {
+  bf16x8 xb[2][PT];
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xb[half][pt] = *(const bf16x8*)(Xt + pt * 2048 + (half ? off1 : off0));
+  bf16x8 wn = *(const bf16x8*)(Wt + off0);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bf16x8 wa = wn;
+      if (nt + 1 < NT) wn = *(const bf16x8*)(Wt + (nt + 1) * 2048 + (half ? off1 : off0));
+      else if (half == 0) wn = *(const bf16x8*)(Wt + off1);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[half][pt], acc[nt][pt], 0, 0, 0);
+      hook(half * NT + nt);
+    }
+  }
+}
+
 // per-lane fragment read offsets (see mfma_chunk)
 DEVFN void frag_offsets(int lane, int& off0, int& off1) {
   const int swz = (lane >> 1) & 7;

@@ -28,10 +28,14 @@ namespace se {
 // SPLIT: the workgroup owns only NT of the layer's row tiles -- group blockIdx.y; for the non-MIXED layouts a group is
 // NT/2 feature tiles plus their NT/2 gate tiles, so the gate stays a register epilogue.  Used with PT = 1 for grids
 // that would leave most CUs idle (one image): 6x (N=192) / 3x (N=96) more, shorter workgroups.
-template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT>
+// BF16: activations and weights stored as bf16 (BASELINE config 5): a granule is 8 channels, a chunk 64 k-values, the
+// MFMA v_mfma_f32_16x16x32_bf16 with fp32 accumulators; bias, activation and gate stay fp32, the gated result is
+// rounded to bf16 once (round to nearest even) when it is stored.  Same gather, same LDS image, same tile geometry.
+template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT, bool BF16>
 __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   constexpr int PIX = PT * 64;
   constexpr int NP = NT * 16;
+  constexpr int ES = BF16 ? 2 : 4;           // bytes per stored element
   constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
   constexpr int NX = PT * 2;                 // X staging pieces (8 rows each) per wave per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     ryx[i] = e.y;
     if (FAST) {
       const int y0 = e.y >> 16, x0 = e.y & 0xffff;       // invalid rows: y0 = 16384, every tap fails the row test
-      pixoff[i] = (unsigned)((e.x * p.Hin + y0) * p.Win + x0) * (unsigned)(p.C0 * 4);
+      pixoff[i] = (unsigned)((e.x * p.Hin + y0) * p.Win + x0) * (unsigned)(p.C0 * ES);
       const int KH = p.magicKH;
       unsigned mask = 0;
       if (p.dil == 1) {
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   frag_offsets(lane, off0, off1);
   const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
 
-  const se_i32x4 rsrc = make_rsrc(p.src0, (unsigned)p.B * p.Hin * p.Win * p.C0 * 4u);
+  const se_i32x4 rsrc = make_rsrc(p.src0, (unsigned)p.B * p.Hin * p.Win * p.C0 * (unsigned)ES);
   // fast path staging, split so that the pieces can be issued one per MFMA step (mfma_chunk hook): a burst of
   // vector-memory instructions fills the CU's queue and stalls the wave (and its MFMAs) in front of it
   constexpr int NWP = (NT * 2 + 3) / 4;          // W staging pieces per wave
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     const int cg = gi - __umul24(tap, p.CG);
     const int ky = __umul24(tap, p.magicKW) >> 8, kx = tap - __umul24(ky, p.KW);
     const int dy = __mul24(ky, p.dil) - pady, dx = __mul24(kx, p.dil) - padx;
-    f_delta = (unsigned)(__mul24(__mul24(dy, p.Win) + dx, p.C0 * 4) + cg * 16);
+    f_delta = (unsigned)(__mul24(__mul24(dy, p.Win) + dx, p.C0 * ES) + cg * 16);
     f_tap = min(tap, 31);
   };
   auto fast_piece = [&](int ch, int buf, int q) {      // q compile-time after unrolling
@@ -149,9 +153,9 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     const int dy = ky * p.dil - pady, dx = kx * p.dil - padx;
     const bool tapok = tap < p.T;
     const bool first = cg < p.C0g;
-    const float* base = first ? p.src0 : p.src1;
-    const int cs = first ? p.C0 : p.C1;
-    const int coff = (first ? cg : cg - p.C0g) * 4;
+    const char* base = (const char*)(first ? p.src0 : p.src1);
+    const int cs = (first ? p.C0 : p.C1) * ES;                  // bytes per pixel
+    const int coff = (first ? cg : cg - p.C0g) * 16;            // byte offset of the granule inside the pixel
     const bool vec = (!first) && p.src1_vec;
     const unsigned xdst = lds_x + buf * XBYTES;
 #pragma unroll
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       iy >>= p.ushift;
       ix >>= p.ushift;
       const unsigned pix = vec ? (unsigned)rb[i] : (unsigned)((rb[i] * p.Hin + iy) * p.Win + ix);
-      const float* g = base + (size_t)(pix * (unsigned)cs + (unsigned)coff);
-      g = ok ? g : p.zeros;
+      const char* g = base + (size_t)pix * (unsigned)cs + (unsigned)coff;
+      g = ok ? g : (const char*)p.zeros;
       glds16(g, xdst + (i * 4 + w) * 1024);
     }
     const unsigned wdst = lds_w + buf * WBYTES;
@@ -195,15 +199,18 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
       if (more) fast_head(ch + 1);
       // ... all within the first k-half of the chunk, so the youngest piece still has half a chunk of MFMAs to land
       constexpr int SLOTS = NT, PER = (NPIECE + SLOTS - 1) / SLOTS;
-      mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, [&](int slot) {
+      auto hook = [&](int slot) {
         if (more) {
 #pragma unroll
           for (int u = 0; u < PER; ++u) fast_piece(ch + 1, buf ^ 1, slot * PER + u);
         }
-      });
+      };
+      if (BF16) mfma_chunk16<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, hook);
+      else mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, hook);
     } else {
       if (ch + 1 < p.nch) stage(ch + 1, buf ^ 1);               // DMA of the next chunk flies under the MFMAs
-      mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+      if (BF16) mfma_chunk16<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+      else mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
     }
     dma_wait_all();
     __syncthreads();
@@ -236,7 +243,10 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
           const float a = p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f);
           o[r] = a * sigmoid_fast(g);
         }
-        if (c0 < p.G && pidx < p.total_pix) *(f32x4*)(p.dst + out_off(pidx) + c0) = o;
+        if (c0 < p.G && pidx < p.total_pix) {
+          if (BF16) *(uint2*)((char*)p.dst + (out_off(pidx) + c0) * 2) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+          else *(f32x4*)(p.dst + out_off(pidx) + c0) = o;
+        }
       }
     }
   } else {
@@ -259,26 +269,29 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
         float2 o;
         o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(g0);
         o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(g1);
-        if (c0 < p.G && pidx < p.total_pix) *(float2*)(p.dst + out_off(pidx) + c0) = o;
+        if (c0 < p.G && pidx < p.total_pix) {
+          if (BF16) *(unsigned*)((char*)p.dst + (out_off(pidx) + c0) * 2) = pack_bf16x2(o.x, o.y);
+          else *(float2*)(p.dst + out_off(pidx) + c0) = o;
+        }
       }
     }
   }
 }
 
-template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT>
+template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT, bool BF16>
 static hipError_t launch_gconv_f(const GConvParams& p, hipStream_t st, int label) {
   constexpr int PIX = PT * 64;
   constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128;
   static_assert(PIX * 8 <= 2 * PIX * 128, "row table aliases the X buffers");
   {
-    hipError_t e = ensure_max_lds((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT>, LDS);
+    hipError_t e = ensure_max_lds((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT, BF16>, LDS);
     if (e != hipSuccess) return e;
   }
   const int tiles = (p.total_pix + PIX - 1) / PIX;
   const int grid = p.up2 ? class_tile_grid(tiles) : tiles;
   const int groups = SPLIT ? p.np_full / (NT * 16) : 1;
   ProfScope ps_(st, label);
-  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT>), dim3(grid, groups), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT, BF16>), dim3(grid, groups), dim3(256), LDS, st, p);
   return hipGetLastError();
 }
 
@@ -286,12 +299,15 @@ static hipError_t launch_gconv_f(const GConvParams& p, hipStream_t st, int label
 static bool fast_eligible(const GConvParams& p) {
   static const bool enabled = !(getenv("SE_GCONV_FAST") && atoi(getenv("SE_GCONV_FAST")) == 0);
   return enabled && p.C0g == p.CG && !p.ushift && p.T <= 31 && p.magicKH * p.KW == p.T &&
-         (long long)p.B * p.Hin * p.Win * p.C0 * 4 < (1ll << 31);
+         (long long)p.B * p.Hin * p.Win * p.C0 * (p.bf16 ? 2 : 4) < (1ll << 31);
 }
 template <int NT, int PT, bool MIXED, int WPS, bool SPLIT = false>
 static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label) {
-  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT>(p, st, label)
-                          : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT>(p, st, label);
+  if (p.bf16)
+    return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT, true>(p, st, label)
+                            : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT, true>(p, st, label);
+  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT, false>(p, st, label)
+                          : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT, false>(p, st, label);
 }
 
 // (A 3-stage LDS ring for the narrow MIXED shapes -- two chunks of DMA in flight, exact vmcnt waits -- was measured

@@ -38,10 +38,10 @@ hipError_t ensure_max_lds(const void* func, int bytes);
 //   one or two NHWC sources (im2col-free); Wp is packed on the host (se_api.hip pack_layer).
 // ---------------------------------------------------------------------------------------------
 struct GConvParams {
-  const float* src0;   // NHWC [B][Hin][Win][C0]
+  const float* src0;   // NHWC [B][Hin][Win][C0]  (fp32, or bf16 when `bf16` is set -- the pointer types stay float*)
   const float* src1;   // optional second source (channel concat): NHWC [B][Hin][Win][C1] or vector [B][C1]
-  const float* wpk;    // packed weights [nch][NP][32] (LDS image, pre-swizzled)
-  const float* bias;   // [NP] in packed-row order
+  const float* wpk;    // packed weights [nch][NP][128 bytes] (LDS image, pre-swizzled): 32 fp32 or 64 bf16 k-values per row
+  const float* bias;   // [NP] in packed-row order (always fp32)
   float* dst;          // NHWC [B][Ho][Wo][G]
   const float* zeros;  // >= 16 bytes of zeros (source of out-of-bounds granules)
   int B, Hin, Win, Ho, Wo;
@@ -67,6 +67,7 @@ struct GConvParams {
   int xcd;             // 1: XCD-aware tile order (se_device.h xcd_tile)
   int np_full;         // packed rows of the whole layer (row count of one chunk of wpk)
   int nf_full;         // feature tiles of the whole layer (non-MIXED layouts: gates start at tile nf_full)
+  int bf16;            // 1: sources, weights and dst are bf16 (granule = 8 channels, chunk = 64 k); C0, C1, G count elements
   int small_grid;      // 1: low-latency launch shape (small pixel tiles; the packed rows split over blockIdx.y) for grids
                        //    that would otherwise leave most of the 256 CUs idle (batch 1)
 };
@@ -132,6 +133,7 @@ struct SmallConvParams {
   long out_bs;         // of out_nchw (mode 0: the soft mask)
   long mask_bs;        // of mask (mode 3: the soft mask)
   long comp_bs;        // of composed
+  int bf16;            // x is bf16 NHWC with a 16-channel pixel stride; xnow (mode 2) is written as bf16 NHWC8
 };
 hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st);
 
@@ -151,7 +153,15 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int C
 hipError_t launch_quantize_u8(const float* composed, const float* mask, unsigned char* rgb, unsigned char* m8, int B, int H,
                               int W, hipStream_t st);
 // column reduce over pixels: x [B][HW][C] -> out [B][C].  op 0 max, 1 mean, 2 rsqrt(sum(x^2)+1e-8)
-hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st);
+// x_bf16: x holds bf16; out_bf16 (optional): a bf16 copy of the result (the style vector as a bf16 conv source)
+hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st,
+                            int x_bf16 = 0, float* out_bf16 = nullptr);
+// bf16 forms of the input packing (NHWC8 bf16 for every network input) and of the unit-test layout converters
+hipError_t launch_pack_m16(const float* image, const float* sketch, float* dst8, int B, int H, int W, hipStream_t st);
+hipError_t launch_pack_g16(const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
+                           float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint, hipStream_t st);
+hipError_t launch_nchw_to_nhwc16(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st);
+hipError_t launch_nhwc16_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st);
 static const int COLREDUCE_SPLITS = 32;
 
 // ---------------------------------------------------------------------------------------------
@@ -175,6 +185,7 @@ struct AttParams {
   float* P;            // [B][R][Rp] workspace: softmax probabilities in class-grid indexing (row = query, column = key)
   float* validR;       // [B][Rp]    workspace: key validity in class-grid indexing: 1 / 0, -1 where the position is not a key
   float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
+  int bf16;            // x, xn, xT, P~ (in the E buffer) and out hold bf16; Rp is then a multiple of 64
 };
 hipError_t launch_attention(const AttParams& p, hipStream_t st);    // p.E != null: space-to-depth form, else the patch form
 bool attention_v2_enabled();

@@ -64,7 +64,9 @@ ProfScope::~ProfScope() {
 // ------------------------------------------------------------------------------------------------
 // final 3x3 conv of each decoder: 12 -> COUT raw, + tanh / sigmoid / composites (VALU, memory bound)
 // ------------------------------------------------------------------------------------------------
-template <int COUT>
+// BF16: the 12-channel input is stored as bf16 NHWC with a 16-channel pixel stride (channels 12-15 are zero); the
+// stage-2 input written by mode 2 is then bf16 NHWC8.  Arithmetic and the NCHW outputs stay fp32.
+template <int COUT, bool BF16>
 __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p) {
   const int HW = p.H * p.W;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -81,9 +83,20 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = x + kx - 1;
       if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-        const f32x4* src = (const f32x4*)(p.x + ((long)(b * p.H + iy) * p.W + ix) * 12);
-        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
-        const float v[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+        float v[12];
+        if (BF16) {
+          const uint4 a = *(const uint4*)((const char*)p.x + ((long)(b * p.H + iy) * p.W + ix) * 32);
+          const uint2 c = *(const uint2*)((const char*)p.x + ((long)(b * p.H + iy) * p.W + ix) * 32 + 16);
+          const unsigned u[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { v[2 * i] = bf16_lo(u[i]); v[2 * i + 1] = bf16_hi(u[i]); }
+        } else {
+          const f32x4* src = (const f32x4*)(p.x + ((long)(b * p.H + iy) * p.W + ix) * 12);
+          const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
+          const float vv[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+#pragma unroll
+          for (int i = 0; i < 12; ++i) v[i] = vv[i];
+        }
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
           const float* wc = p.w + (c * 9 + ky * 3 + kx) * 12;
@@ -122,7 +135,8 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p
         o[c] = p.no_mask_coarse ? t[c] : t[c] * m + xin * (1.f - m);
       }
       o[3] = 0.f;
-      *(f32x4*)(p.xnow + idx * 4) = o;
+      if (BF16) *(uint4*)((char*)p.xnow + idx * 16) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], 0.f), 0u, 0u);
+      else *(f32x4*)(p.xnow + idx * 4) = o;
     } else if (p.mode == 3 && p.composed) {
       const float m = p.mask[p.mask_bs ? (long)b * p.mask_bs + rem : idx];
       const long cb = p.comp_bs ? (long)b * p.comp_bs : (long)b * 3 * HW;
@@ -139,10 +153,14 @@ hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st) {
   const long n = (long)p.B * p.H * p.W;
   const int grid = (int)((n + 255) / 256);
   ProfScope ps_(st, PL_SMALL_CONV);
-  if (p.cout == 1)
-    hipLaunchKernelGGL(small_conv_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+  if (p.cout == 1 && !p.bf16)
+    hipLaunchKernelGGL((small_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, p);
+  else if (p.cout == 3 && !p.bf16)
+    hipLaunchKernelGGL((small_conv_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
+  else if (p.cout == 1)
+    hipLaunchKernelGGL((small_conv_kernel<1, true>), dim3(grid), dim3(256), 0, st, p);
   else if (p.cout == 3)
-    hipLaunchKernelGGL(small_conv_kernel<3>, dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((small_conv_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
@@ -206,6 +224,82 @@ hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, con
   ProfScope ps_(st, PL_PACK);
   hipLaunchKernelGGL(pack_g_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x2, mask, mask2, guide,
                      coarse8, style8, B, H * W, no_mask_cc, joint);
+  return hipGetLastError();
+}
+
+// bf16 forms (BASELINE config 5): every network input becomes one 16-byte granule per pixel (NHWC8 bf16)
+__global__ void pack_m16_kernel(const float* __restrict__ image, const float* __restrict__ sketch, uint4* __restrict__ dst,
+                                int B, int HW) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW) return;
+  const int b = idx / HW, rem = idx - (long)b * HW;
+  dst[idx] = make_uint4(pack_bf16x2(image[((long)b * 3 + 0) * HW + rem], image[((long)b * 3 + 1) * HW + rem]),
+                        pack_bf16x2(image[((long)b * 3 + 2) * HW + rem], sketch[idx]), 0u, 0u);
+}
+hipError_t launch_pack_m16(const float* image, const float* sketch, float* dst8, int B, int H, int W, hipStream_t st) {
+  const long n = (long)B * H * W;
+  ProfScope ps_(st, PL_PACK);
+  hipLaunchKernelGGL(pack_m16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, image, sketch, (uint4*)dst8, B, H * W);
+  return hipGetLastError();
+}
+__global__ void pack_g16_kernel(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ mask,
+                                const float* __restrict__ mask2, const float* __restrict__ guide, uint4* __restrict__ coarse8,
+                                uint4* __restrict__ style8, int B, int HW, int no_mask_cc, int joint) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * HW) return;
+  const int b = idx / HW, rem = idx - (long)b * HW;
+  const float m = mask[idx], m2 = mask2[idx], g = guide[idx];
+  float c[3], s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const long o = ((long)b * 3 + k) * HW + rem;
+    c[k] = x[o] * (1.f - m);                        // editline_g.py:124
+    s[k] = no_mask_cc ? x2[o] : x2[o] * m2;         // :120-123
+  }
+  coarse8[idx] = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], g), pack_bf16x2(m, 0.f), 0u);      // :131
+  // joint_train_inp: (x2*m2, m2) -- the guide channel is guide * 0 (:132-133), wconv1 runs without that weight column
+  style8[idx] = joint ? make_uint4(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], m2), 0u, 0u)
+                      : make_uint4(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], g), pack_bf16x2(m2, 0.f), 0u);
+}
+hipError_t launch_pack_g16(const float* x, const float* x2, const float* mask, const float* mask2, const float* guide,
+                           float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint, hipStream_t st) {
+  const long n = (long)B * H * W;
+  ProfScope ps_(st, PL_PACK);
+  hipLaunchKernelGGL(pack_g16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x2, mask, mask2, guide,
+                     (uint4*)coarse8, (uint4*)style8, B, H * W, no_mask_cc, joint);
+  return hipGetLastError();
+}
+// unit-test layout converters: NCHW fp32 <-> NHWC bf16 with a padded channel stride
+__global__ void nchw_to_nhwc16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int B, int C, int Cpad,
+                                      int HW) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*HW*Cpad
+  if (idx >= (long)B * HW * Cpad) return;
+  const int c = idx % Cpad;
+  const long pix = idx / Cpad;
+  const int b = pix / HW, rem = pix - (long)b * HW;
+  dst[idx] = (unsigned short)(pack_bf16x2(c < C ? src[((long)b * C + c) * HW + rem] : 0.f, 0.f) & 0xffffu);
+}
+hipError_t launch_nchw_to_nhwc16(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st) {
+  const long n = (long)B * H * W * Cpad;
+  ProfScope ps_(st, PL_LAYOUT);
+  hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (unsigned short*)dst, B, C,
+                     Cpad, H * W);
+  return hipGetLastError();
+}
+__global__ void nhwc16_to_nchw_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int B, int C, int Cs,
+                                      int HW) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over B*C*HW (NCHW order)
+  if (idx >= (long)B * C * HW) return;
+  const int rem = idx % HW;
+  const long bc = idx / HW;
+  const int c = bc % C, b = bc / C;
+  dst[idx] = __uint_as_float((unsigned)src[((long)b * HW + rem) * Cs + c] << 16);
+}
+hipError_t launch_nhwc16_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st) {
+  const long n = (long)B * C * H * W;
+  ProfScope ps_(st, PL_LAYOUT);
+  hipLaunchKernelGGL(nhwc16_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const unsigned short*)src, dst,
+                     B, C, Cstride, H * W);
   return hipGetLastError();
 }
 
@@ -282,6 +376,7 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int C
 // ------------------------------------------------------------------------------------------------
 // column reduce over pixels (global max pool / mean / L2 norm), deterministic two-stage
 // ------------------------------------------------------------------------------------------------
+template <bool BF16>
 __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                                 int HW, int C, int op) {
   // grid (SPLITS, B); block 256 threads = (256/C' groups) ... generic: thread t handles channel t%C, pixel lane t/C
@@ -294,7 +389,8 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __r
   float a = op == 0 ? -INFINITY : 0.f;
   if (g < groups) {
     for (int pp = p0 + g; pp < p1; pp += groups) {
-      const float v = x[((long)b * HW + pp) * C + c];
+      const float v = BF16 ? __uint_as_float((unsigned)((const unsigned short*)x)[((long)b * HW + pp) * C + c] << 16)
+                           : x[((long)b * HW + pp) * C + c];
       a = op == 0 ? fmaxf(a, v) : (op == 1 ? a + v : fmaf(v, v, a));
     }
   }
@@ -309,8 +405,8 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __r
     partial[((long)b * COLREDUCE_SPLITS + sp) * C + threadIdx.x] = r;
   }
 }
-__global__ void colreduce_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int HW, int C, int op,
-                                       int total) {
+__global__ void colreduce_final_kernel(const float* __restrict__ partial, float* __restrict__ out, unsigned short* out16,
+                                       int HW, int C, int op, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;   // over B*C
   if (idx >= total) return;
   const int b = idx / C, c = idx - b * C;
@@ -322,13 +418,16 @@ __global__ void colreduce_final_kernel(const float* __restrict__ partial, float*
   if (op == 1) r = r / (float)HW;
   if (op == 2) r = 1.f / sqrtf(r + 1e-8f);
   out[idx] = r;
+  if (out16) out16[idx] = (unsigned short)(pack_bf16x2(r, 0.f) & 0xffffu);
 }
-hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st) {
+hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st,
+                            int x_bf16, float* out_bf16) {
   if (C > 256) return hipErrorInvalidValue;
   ProfScope ps_(st, PL_COLREDUCE);
-  hipLaunchKernelGGL(colreduce_partial_kernel, dim3(COLREDUCE_SPLITS, B), dim3(256), 0, st, x, partial, HW, C, op);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, partial, out, HW, C, op,
-                     B * C);
+  if (x_bf16) hipLaunchKernelGGL(colreduce_partial_kernel<true>, dim3(COLREDUCE_SPLITS, B), dim3(256), 0, st, x, partial, HW, C, op);
+  else hipLaunchKernelGGL(colreduce_partial_kernel<false>, dim3(COLREDUCE_SPLITS, B), dim3(256), 0, st, x, partial, HW, C, op);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, partial, out,
+                     (unsigned short*)out_bf16, HW, C, op, B * C);
   return hipGetLastError();
 }
 

@@ -78,6 +78,44 @@ def run_case(m, B, H, W, seed):
     return {k: v.numpy() for k, v in out.items()}
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def run_case_bf16(gain, B, H, W, seed):
+    """BASELINE config 5 comparator: the REFERENCE forward with bf16 roundings injected from outside -- conv weights
+    rounded to bf16 in the state dict, a forward pre-hook on every gen_conv / gen_deconv that rounds the tensor it
+    reads, a forward hook that rounds every gated output (raw 12->3 / 12->1 outputs stay fp32) and the attention
+    output.  The reference cannot be made to round INSIDE its attention (keys, probabilities): the oracle's bf16 mode
+    does, and tests/test_oracle_golden.py bounds the difference."""
+    m = build_reference(gain)
+    from models.networks.utils import gen_conv
+    for net in (m.netG, m.netM):
+        sd = net.state_dict()
+        net.load_state_dict({k: (_bf16(v) if k.endswith(".weight") else v) for k, v in sd.items()})
+    hooks = []
+    for net in (m.netG, m.netM):
+        for mod in net.modules():
+            if isinstance(mod, gen_conv):
+                hooks.append(mod.register_forward_pre_hook(lambda mod, inp: (_bf16(inp[0]),)))
+                gated = not (mod.out_channels == 3 or mod.activation is None)
+                if gated:
+                    hooks.append(mod.register_forward_hook(lambda mod, inp, out: _bf16(out)))
+    hooks.append(m.netG.cam_2.register_forward_hook(lambda mod, inp, out: (_bf16(out[0]),) + tuple(out[1:])))
+    img, sk = synth.make_inputs(B, H, W, seed=seed)
+    img, sk = torch.from_numpy(img), torch.from_numpy(sk)
+    with torch.no_grad():
+        composed, soft = m({"image": img, "mask": sk, "gt": img, "edgegt": sk}, mode="inference")
+        mask, mask_image = m.netM(img, sk)
+        hard = (mask > 0.5).float()
+        coarse, fine = m.netG(img, img, hard, hard, sk)
+    for h in hooks:
+        h.remove()
+    assert torch.equal(soft, mask)
+    return {k: v.numpy().astype(np.float32) for k, v in dict(composed=composed, mask=mask, mask_image=mask_image,
+                                                             hard_mask=hard, coarse=coarse, fine=fine).items()}
+
+
 def summary(a):
     a = a.astype(np.float64)
     return np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.min(), a.max()], np.float64)
@@ -186,6 +224,11 @@ def main():
     kb["hard_mask_bits"] = np.packbits(big["hard_mask"].astype(np.uint8))
     kb["meta"] = np.array([gain, 0, 1234, 1, 256, 256], np.float64)
     np.savez_compressed(os.path.join(HERE, "e2e_256.npz"), **kb)
+    # ---- bf16 comparator (BASELINE config 5): reference + rounding hooks, 64x64 B=2 ---------------------------
+    b16 = run_case_bf16(gain, 2, 64, 64, seed=1234)
+    print("bf16 64x64: |composed - fp32| max %.4f  hard-mask flips vs fp32 %d" % (
+        np.abs(b16["composed"] - small["composed"]).max(), int((b16["hard_mask"] != small["hard_mask"]).sum())))
+    np.savez_compressed(os.path.join(HERE, "e2e_64_bf16.npz"), meta=np.array([gain, 0, 1234, 2, 64, 64], np.float64), **b16)
     # ---- per-op known answers ------------------------------------------------------
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **op_cases())
     for f in sorted(os.listdir(HERE)):

@@ -200,3 +200,37 @@ def test_c_oracle_deconv_and_attention(golden_dir):
     out, sim = ref_ops.attention(xa.numpy(), np.ones((2, 1, 48, 64), np.float32))
     assert _maxdiff(sim, g["op.att_allinvalid.similar"]) < TOL
     assert _maxdiff(out, g["op.att_allinvalid.out"]) < 1e-5
+
+
+# ---- bf16 mode (BASELINE config 5) -------------------------------------------------------------------------------------
+def test_bf16_mode_pinned_by_reference_with_rounding_hooks(golden_dir):
+    """e2e_64_bf16.npz = the REFERENCE forward with bf16 roundings injected through module hooks (conv weights, every
+    tensor a conv reads, every gated output, the attention output).  The oracle's bf16 mode places the same roundings and
+    must reproduce it exactly wherever the hooks can reach: all of netM and netG's stage 1.  Stage 2 contains the
+    attention block, inside which the oracle additionally rounds the keys and the probabilities (a bf16 kernel has to;
+    hooks cannot): bounded."""
+    g = _load(golden_dir, "e2e_64_bf16.npz")
+    gain, wseed, iseed, B, H, W = g["meta"]
+    WM, WG = _weights(float(gain))
+    img, sk = synth.make_inputs(int(B), int(H), int(W), seed=int(iseed))
+    bf = torch.bfloat16
+    with torch.no_grad():
+        mask, mask_image = O.netM_forward(WM, img, sk, act_dtype=bf)
+        hard = torch.from_numpy(g["hard_mask"])
+        coarse, fine = O.netG_forward(WG, img, img, hard, hard, sk, act_dtype=bf)
+    assert _maxdiff(mask, g["mask"]) == 0.0 and _maxdiff(mask_image, g["mask_image"]) == 0.0
+    assert np.array_equal((mask > 0.5).float().numpy(), g["hard_mask"])
+    assert _maxdiff(coarse, g["coarse"]) == 0.0
+    assert _maxdiff(fine, g["fine"]) < 1e-2
+    # and it is a bf16 computation: close to, not equal to, the fp32 reference
+    g32 = _load(golden_dir, "e2e_64.npz")
+    assert 1e-4 < _maxdiff(g["mask"], g32["mask"]) < 5e-2 and _maxdiff(g["fine"], g32["fine"]) < 0.25
+    r = O.inference(WM, WG, img, sk, act_dtype=bf)
+    assert np.array_equal(r["hard_mask"].numpy(), g["hard_mask"])
+    assert _maxdiff(r["composed"], g["composed"]) < 1e-2
+
+
+def test_bf16_mode_leaves_fp32_mode_untouched(e2e64):
+    g, r = e2e64
+    assert O._DT[0] is None
+    assert _maxdiff(r["fine"], g["fine"]) < TOL
