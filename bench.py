@@ -55,6 +55,7 @@ LIVE_GFLOP_PER_IMAGE = {256: 90.80, 512: 437.27}
 KERNEL_LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96",
                  "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96", "gconv_kernel<3": "gconv_n48",
                  "gconv_kernel<2": "gconv_n24", "att2_pair_kernel": "att_score", "att2_pv_kernel": "att_pv",
+                 "att2_softmax": "att_softmax", "att2_boxsum_kernel": "att_boxsum",
                  "att_score_kernel": "att_score", "att_pv_kernel": "att_pv"}
 
 
@@ -326,6 +327,13 @@ def main():
                   "max_abs_mask": float((r1["mask"].cpu() - ref["mask"]).abs().max()),
                   "hard_mask_flips": flips, "image": 0, "tolerance": 1e-3 if args.dtype == "f32" else None,
                   "comparator": "fp32 oracle"}
+        if flips and args.dtype == "f32":
+            # a soft-mask value within float noise of 0.5 thresholded differently (editline2_model.py:347): netG then saw a
+            # different INPUT.  The composite is re-checked against the oracle's netG on the hard mask this run used.
+            hard = r1["hard"].cpu()
+            _, fine2 = O.netG_forward(WG, img_h[:1], img_h[:1], hard, hard, sk_h[:1])
+            comp2 = fine2 * ref["mask"] + torch.from_numpy(img_h[:1]) * (1 - ref["mask"])
+            parity["max_abs_composed_same_hard_mask"] = float((r1["composed"].cpu() - comp2).abs().max())
         if args.dtype == "bf16":
             # the comparator of the bf16 path is the oracle's bf16 mode (same roundings, fp32 accumulation); netG is
             # compared on the oracle's hard mask so that a threshold flip does not change its input

@@ -95,6 +95,13 @@ int se_inference(se_ctx* ctx, void* stream, const float* image, const float* ske
                  float* mask_out, float* hard_out, float* maskim_out, float* coarse_out, float* fine_out,
                  void* workspace, size_t workspace_bytes, int B, int H, int W, int flags);
 
+/* se_inference with the output quantisation of test.py:25-27 fused into its last kernel: rgb_out (B,H,W,3) uint8 =
+ * trunc((composed + 1) / 2 * 255) in the HWC order test.py:35 transposes to, mask_u8_out (B,H,W) uint8 = trunc(mask * 255)
+ * (may be NULL); same fp32 operation order as the reference's tensor expressions, no clamp.  No fp32 output tensor is
+ * written at all.  flags as se_inference (GRAPH and PACKED_OUT are ignored). */
+int se_inference_u8(se_ctx* ctx, void* stream, const float* image, const float* sketch, unsigned char* rgb_out,
+                    unsigned char* mask_u8_out, void* workspace, size_t workspace_bytes, int B, int H, int W, int flags);
+
 /* Output quantisation of test.py:25-27 on the device: rgb_out (B,H,W,3) uint8 = trunc((composed + 1) / 2 * 255)
  * in the HWC order test.py:35 transposes to, mask_u8_out (B,H,W) uint8 = trunc(mask * 255); same fp32 operation
  * order as the reference's tensor expressions, no clamp (as test.py; demo.py:62 clamps -- a [-1,1] input cannot

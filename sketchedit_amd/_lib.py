@@ -25,7 +25,7 @@ LOW_LATENCY_MAX_PIXELS = 2 * 256 * 256
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
-           "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_inference", "se_gated_conv2d",
+           "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_inference", "se_inference_u8", "se_gated_conv2d",
            "se_gated_conv2d_ex", "se_attention", "se_attention_ex", "se_quantize_u8", "se_profile_enable",
            "se_profile_report"]
 
@@ -86,6 +86,8 @@ def load_library():
         lib.se_netG_forward.restype = ci
         lib.se_inference.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
         lib.se_inference.restype = ci
+        lib.se_inference_u8.argtypes = [vp, vp, c_f, c_f, vp, vp, vp, sz, ci, ci, ci, ci]
+        lib.se_inference_u8.restype = ci
         lib.se_gated_conv2d.argtypes = [vp, vp, c_f, c_f, c_f, c_f] + [ci] * 10
         lib.se_gated_conv2d.restype = ci
         lib.se_gated_conv2d_ex.argtypes = [vp, vp, c_f, c_f, ci, c_f, c_f, c_f] + [ci] * 12
@@ -315,6 +317,21 @@ class Engine:
         call(ctypes.c_void_p(gs.cuda_stream))
         cur.wait_stream(gs)
         return r
+
+    def inference_u8(self, image, sketch, flags, low_latency=None):
+        """The forward with test.py:25-27's quantisation fused into its last kernel -> (rgb (B,H,W,3) uint8, mask (B,H,W)
+        uint8): what test.py writes to disk, without an fp32 output tensor or a separate pass."""
+        import torch
+        _check_dev(image, sketch)
+        B, _, H, W = image.shape
+        ws = self.workspace(B, H, W)
+        rgb = torch.empty((B, H, W, 3), dtype=torch.uint8, device=image.device)
+        m8 = torch.empty((B, H, W), dtype=torch.uint8, device=image.device)
+        flags = (flags & 31) | self.exec_flags(B, H, W, low_latency, False)
+        if self.lib.se_inference_u8(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(rgb), _ptr(m8), _ptr(ws),
+                                    ws.numel(), B, H, W, flags):
+            self._err("se_inference_u8")
+        return rgb, m8
 
     def inference_packed(self, image, sketch, flags, out, low_latency=None):
         """Inference into ONE (B,4,H,W) buffer `out`: planes 0-2 composed, plane 3 the soft mask -- the unit the

@@ -140,6 +140,8 @@ struct se_ctx {
   bool dry = false;
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
+  unsigned char* rgb8 = nullptr;   // se_inference_u8: uint8 outputs written by the last kernel of the running call
+  unsigned char* m8 = nullptr;
   Profiler prof;
   struct Peaks { size_t main, side; };
   std::map<std::vector<long long>, Peaks> peaks;      // dry-run arena peaks per (B, H, W, flags, outputs wanted)
@@ -799,6 +801,7 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
     sp.bf16 = c->bf16 ? 1 : 0;
     sp.mode = mode; sp.out_nchw = out_nchw; sp.hard = hard; sp.img = img; sp.mask = mask; sp.xnow = xnow;
     sp.composed = composed; sp.no_mask_coarse = no_mask_coarse;
+    if (mode == 3) { sp.rgb8 = c->rgb8; sp.m8 = c->m8; }
     if (packed_bs) {      // SE_FLAG_PACKED_OUT: soft mask and composite live in one (B,4,H,W) buffer
       if (mode == 0) sp.out_bs = packed_bs;
       if (mode == 3) { sp.mask_bs = packed_bs; sp.comp_bs = packed_bs; }
@@ -908,7 +911,17 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   Act d2 = decoder(P, "allconv", hallu, pm.p, 96, 0);   // cat([x_hallu, pm]) :211 is virtual
   P.free(pm);
   small(P, "allconv17", d2, 3, fine_out, nullptr, x, soft_mask, nullptr, soft_mask ? composed_out : nullptr, 0, packed_bs);
+  c->rgb8 = nullptr; c->m8 = nullptr;
   return P.rc;
+}
+
+// Row stride (in elements) of the R x R matrices E, P, P~ and of the transposed values: R rounded up to whole k-chunks
+// (32 fp32 / 64 bf16 keys).  (Padding the power-of-two strides of 256x256 / 512x512 inputs by one chunk was measured:
+// no gain for the row-streaming passes -- they are not camping on HBM channels.)
+int att_row_stride(int R, bool bf) {
+  const int chunk = bf ? 64 : 32;
+  int Rp = (R + chunk - 1) / chunk * chunk;
+  return Rp;
 }
 
 int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, float* similar_nchw) {
@@ -916,7 +929,8 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
   const int hs = (h - 4) / 2 + 1, ws = (w - 4) / 2 + 1, L = hs * ws, Lp = (L + 31) & ~31;
   const bool bf = c->bf16;
   const bool v2 = attention_v2_enabled() || bf;       // the bf16 path exists in the space-to-depth form only
-  const int hc = h / 2, wc = w / 2, R = hc * wc, Rp = bf ? (R + 63) & ~63 : (R + 31) & ~31;
+  const int hc = h / 2, wc = w / 2, R = hc * wc;
+  const int Rp = att_row_stride(R, bf);
   if (v2 && (double)R * Rp * 4.0 >= 2147483648.0) return P.rc = fail(c, "attention: %dx%d feature map too large", h, w);
   // fp32 scratch is sized in floats whatever the activation type
   float* part = P.alloc_raw((size_t)B * COLREDUCE_SPLITS * 96);
@@ -1008,6 +1022,7 @@ void begin_call(se_ctx* c, void* stream, int flags) {
   c->dry = false;
   c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
   c->bf16 = (flags & SE_FLAG_BF16) != 0;
+  c->rgb8 = nullptr; c->m8 = nullptr;
   set_profiler(&c->prof);
 }
 
@@ -1139,7 +1154,7 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
         const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, true);
         if (pk.main + pk.side > peak) peak = pk.main + pk.side;
       }
-  return peak + (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask plane used by se_inference
+  return peak + 2 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes
 }
 
 int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
@@ -1241,6 +1256,30 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   }
   HIPCHK(c, hipGraphLaunch(ge->exec, (hipStream_t)stream));
   return 0;
+}
+
+// The forward with the output quantisation of test.py:25-27 fused into its last kernel: the composite and the soft mask
+// leave the device as uint8 only (a quarter of the fp32 bytes, no separate pass); the soft mask needed between netM and
+// the final composite lives in the workspace.
+int se_inference_u8(se_ctx* c, void* stream, const float* image, const float* sketch, unsigned char* rgb_out,
+                    unsigned char* mask_u8_out, void* ws, size_t ws_bytes, int B, int H, int W, int flags) {
+  if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (check_dims(c, B, H, W)) return 1;
+  if (!image || !sketch || !rgb_out || !ws) return fail(c, "null pointer argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  flags &= ~(SE_FLAG_GRAPH | SE_FLAG_PACKED_OUT);
+  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
+  const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, false);
+  if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
+  float* hard = (float*)((char*)ws + ws_bytes - plane);
+  float* soft = (float*)((char*)ws + ws_bytes - 2 * plane);
+  begin_call(c, stream, flags);
+  int rc = plan_netM(c, image, sketch, soft, hard, nullptr, B, H, W);
+  if (rc) return rc;
+  if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
+  c->rgb8 = rgb_out; c->m8 = mask_u8_out;
+  return plan_netG(c, image, image, hard, hard, sketch, nullptr, nullptr, soft, nullptr, B, H, W, flags);
 }
 
 // test.py:25-27 on the device
@@ -1402,7 +1441,7 @@ int se_attention_ex(se_ctx* c, void* stream, const float* x, const float* mask_f
   HIPCHK(c, hipSetDevice(c->device));
   begin_call(c, stream, exec_flags & SE_FLAG_BF16);
   const bool bf = c->bf16;
-  const int R = (h / 2) * (w / 2), Rp = (R + 63) & ~63;
+  const int R = (h / 2) * (w / 2), Rp = att_row_stride(R, true) + 64;
   const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (1 + 4 * 96) + 64 * 96 * B) * 4 + (1 << 16);
   char* ws = nullptr;
   HIPCHK(c, hipMalloc(&ws, bytes));

@@ -480,14 +480,28 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   }
 }
 
+// Row order of the two streaming passes.  Row r of E is read by the 4 queries r - d, row i of P by the 4 rows i + d: with
+// one wave per row in plain row-major order the second pair of readers comes a whole grid row later, on another XCD, and
+// every row is fetched from HBM ~4 times (measured: 2.8 TB/s of traffic for 1 GB of E).  Waves are therefore assigned
+// in 8x8 tiles of the grid, and every XCD walks a contiguous range of tiles (xcd_tile): the readers of a row run within
+// a few blocks of each other on one L2.  q -> (image, y, x) on an ny x nx grid; false for the padding of ragged tiles.
+DEVFN bool tile_order(long q, int B, int ny, int nx, int& b, int& y, int& x) {
+  const int ty = (ny + 7) >> 3, tx = (nx + 7) >> 3;
+  const long per = (long)ty * tx * 64;
+  b = (int)(q / per);
+  const int rem = (int)(q - (long)b * per), t = rem >> 6, in = rem & 63;
+  y = (t / tx) * 8 + (in >> 3);
+  x = (t % tx) * 8 + (in & 7);
+  return b < B && y < ny && x < nx;
+}
+static inline long tile_order_count(int B, int ny, int nx) { return (long)B * ((ny + 7) >> 3) * ((nx + 7) >> 3) * 64; }
+
 // One wave per query i: S[j] = scale * valid[j] * sum_d E[i+d][j+d] (splitcam.py:69,90,104), softmax over the keys
 // (:105); written in class-grid indexing, zero at the grid positions that are not keys and in the pad columns.
 __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
-  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qi >= (long)p.B * p.L) return;
-  const int b = qi / p.L, i = qi - (long)b * p.L;
-  const int iy = i / p.ws, ix = i - iy * p.ws;
+  int b, iy, ix;
+  if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hs, p.ws, b, iy, ix)) return;
   const int r0 = iy * p.wc + ix;
   const float* E0 = p.E + ((size_t)b * p.R + r0) * p.Rp;      // (iy, ix)
   const float* E1 = E0 + p.Rp;                                // (iy, ix+1)
@@ -529,10 +543,8 @@ __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
 template <int NV>
 __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
-  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qi >= (long)p.B * p.L) return;
-  const int b = qi / p.L, i = qi - (long)b * p.L;
-  const int iy = i / p.ws, ix = i - iy * p.ws;
+  int b, iy, ix;
+  if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hs, p.ws, b, iy, ix)) return;
   const int r0 = iy * p.wc + ix;
   const float* E0 = p.E + ((size_t)b * p.R + r0) * p.Rp;
   const float* E1 = E0 + p.Rp;
@@ -543,16 +555,32 @@ __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p
   const int o2 = p.wc, o3 = p.wc + 1;
   float v[NV];
   float m = -INFINITY;
+  // Every load is unconditional (clamped index, the value is selected afterwards) and the loads of 16 columns are
+  // issued as one batch in front of a scheduling barrier: left alone, hipcc emits load / wait / add for each of the 5
+  // operands of each column in turn -- ~130 dependent memory round trips per wave -- and the pass is latency-bound.
+  const int smax = p.R - 1 - o3;              // the largest key position: s + wc + 1 stays inside the row
+  constexpr int BATCH = 16;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int s = lane + 64 * k;
-    float sc = -INFINITY;                     // not a key: exp() below gives 0
-    if (s < p.R) {
-      const float vv = vr[s];
-      if (vv >= 0.f) sc = (E0[s] + E1[s + 1] + E2[s + o2] + E3[s + o3]) * vv * p.scale;
+  for (int k0 = 0; k0 < NV; k0 += BATCH) {
+    float a0[BATCH], a1[BATCH], a2[BATCH], a3[BATCH], vv[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int sl = min(lane + 64 * (k0 + j), smax);
+      vv[j] = vr[sl];
+      a0[j] = E0[sl];
+      a1[j] = E1[sl + 1];
+      a2[j] = E2[sl + o2];
+      a3[j] = E3[sl + o3];
     }
-    v[k] = sc;
-    m = fmaxf(m, sc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int s = lane + 64 * (k0 + j);
+      const float sc = (a0[j] + a1[j] + a2[j] + a3[j]) * vv[j] * p.scale;
+      v[k0 + j] = (s <= smax && vv[j] >= 0.f) ? sc : -INFINITY;      // not a key: exp() below gives 0
+      m = fmaxf(m, v[k0 + j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -577,10 +605,9 @@ __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p
 template <bool BF16>
 __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
-  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qi >= (long)p.B * p.R) return;
-  const int b = qi / p.R, r = qi - (long)b * p.R;
-  const int ry = r / p.wc, rx = r - ry * p.wc;
+  int b, ry, rx;
+  if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hc, p.wc, b, ry, rx)) return;
+  const int r = ry * p.wc + rx;
   const float* Pb = p.P + (size_t)b * p.R * p.Rp;
   // row r of P~: fp32, or bf16 packed into the front half of the E buffer (rounded once, here)
   char* out = (char*)p.E + ((size_t)b * p.R + r) * p.Rp * (BF16 ? 2 : 4);
@@ -593,20 +620,33 @@ __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
     src[d] = ok ? Pb + (size_t)(qy * p.wc + qx) * p.Rp : nullptr;
     off[d] = dy * p.wc + dx;
   }
-#pragma unroll 4
-  for (int s0 = 2 * lane; s0 < p.Rp; s0 += 128) {        // Rp is even: two columns per lane
-    float a[2] = {0.f, 0.f};
+  // two adjacent columns per lane, 4 column pairs per batch: 32 unconditional loads in front of a scheduling barrier
+  // (see att2_softmax_reg_kernel); a row that does not exist (src null, wave-uniform) reads row 0 of P and is masked
+  const float* rowp[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int s = s0 + u;
-      if (s < p.R) {
+  for (int d = 0; d < 4; ++d) rowp[d] = src[d] ? src[d] : Pb;
+  for (int s00 = 2 * lane; s00 < p.Rp; s00 += 512) {        // Rp is even
+    float v[4][2][4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          if (src[d] && s >= off[d]) a[u] += src[d][s - off[d]];
-      }
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[g][u][d] = rowp[d][min(max(s00 + g * 128 + u - off[d], 0), p.Rp - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int s0 = s00 + g * 128;
+      if (s0 >= p.Rp) break;
+      float a[2] = {0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) a[u] += (src[d] && s0 + u >= off[d] && s0 + u < p.R) ? v[g][u][d] : 0.f;
+      if (BF16) *(unsigned*)(out + s0 * 2) = pack_bf16x2(a[0], a[1]);
+      else *(float2*)(out + s0 * 4) = make_float2(a[0], a[1]);
     }
-    if (BF16) *(unsigned*)(out + s0 * 2) = pack_bf16x2(a[0], a[1]);
-    else *(float2*)(out + s0 * 4) = make_float2(a[0], a[1]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -713,7 +753,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
     hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
   }
   {
-    const long rows = (long)p.B * p.L;
+    const long rows = tile_order_count(p.B, p.hs, p.ws);
     ProfScope ps_(st, PL_ATT_SOFTMAX);
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (p.Rp <= 64 * 16) hipLaunchKernelGGL(att2_softmax_reg_kernel<16>, grid, dim3(256), 0, st, p);
@@ -726,7 +766,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
     hipLaunchKernelGGL(att2_similar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
   }
   {
-    const long rows = (long)p.B * p.R;
+    const long rows = tile_order_count(p.B, p.hc, p.wc);
     ProfScope ps_(st, PL_ATT_BOXSUM);
     hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   }

@@ -134,6 +134,9 @@ struct SmallConvParams {
   long mask_bs;        // of mask (mode 3: the soft mask)
   long comp_bs;        // of composed
   int bf16;            // x is bf16 NHWC with a 16-channel pixel stride; xnow (mode 2) is written as bf16 NHWC8
+  // mode 3: the output quantisation of test.py:25-27 fused into this last kernel (either may be null)
+  unsigned char* rgb8; // (B,H,W,3) uint8 = trunc((composed + 1) / 2 * 255)
+  unsigned char* m8;   // (B,H,W)   uint8 = trunc(soft mask * 255)
 };
 hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st);
 

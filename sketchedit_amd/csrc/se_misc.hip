@@ -137,14 +137,18 @@ __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p
       o[3] = 0.f;
       if (BF16) *(uint4*)((char*)p.xnow + idx * 16) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], 0.f), 0u, 0u);
       else *(f32x4*)(p.xnow + idx * 4) = o;
-    } else if (p.mode == 3 && p.composed) {
+    } else if (p.mode == 3 && (p.composed || p.rgb8 || p.m8)) {
       const float m = p.mask[p.mask_bs ? (long)b * p.mask_bs + rem : idx];
       const long cb = p.comp_bs ? (long)b * p.comp_bs : (long)b * 3 * HW;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float im = p.img[((long)b * 3 + c) * HW + rem];
-        p.composed[cb + (long)c * HW + rem] = t[c] * m + im * (1.f - m);   // editline2_model.py:132
+        const float v = t[c] * m + im * (1.f - m);                              // editline2_model.py:132
+        if (p.composed) p.composed[cb + (long)c * HW + rem] = v;
+        // test.py:25-27: (x + 1) / 2 * 255 -> uint8, same fp32 operation order, truncation, no clamp; HWC as test.py:35
+        if (p.rgb8) p.rgb8[idx * 3 + c] = (unsigned char)(int)(((v + 1.f) * 0.5f) * 255.f);
       }
+      if (p.m8) p.m8[idx] = (unsigned char)(int)(m * 255.f);
     }
   }
 }

@@ -68,6 +68,17 @@ class EditLine2Model(torch.nn.Module):
         data["edgegt"] = data["edgegt"].to(dev) if "edgegt" in data else data["mask"]
         return data["image"], data["gt"], data["mask"], data["edgegt"], None
 
+    def inference_u8(self, data):
+        """mode='inference' followed by test.py:25-27 -- `((generated + 1) / 2 * 255).astype(uint8)` in HWC order and
+        `(mask * 255).astype(uint8)` -- as ONE library call: the quantisation is fused into the forward's last kernel, so
+        only uint8 leaves the device.  -> (rgb (B,H,W,3) uint8, mask (B,H,W) uint8), both on the device."""
+        inputs, _, line, _, _ = self.preprocess_input(data)
+        if self.training:
+            raise NotImplementedError("call model.eval() first: only the eval branch of generate_fake exists here")
+        eng = self.engine()
+        with torch.no_grad():
+            return eng.inference_u8(inputs.float().contiguous(), line.float().contiguous(), _lib.flags_from_opt(self.opt))
+
     def forward(self, data, mode):
         inputs, real_image, line, line_full, _ = self.preprocess_input(data)
         if mode not in ("inference", "visualize"):

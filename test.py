@@ -18,7 +18,6 @@ import torch
 from PIL import Image
 
 from sketchedit_amd import data, models
-from sketchedit_amd._lib import shared_engine
 from sketchedit_amd.options.test_options import TestOptions
 
 
@@ -41,11 +40,9 @@ def main(argv=None):
     for i, data_i in enumerate(dataloader):
         if i * opt.batchSize >= opt.how_many:
             break
-        with torch.no_grad():
-            generated, mask = model(data_i, mode="inference")
-        # (x+1)/2*255 and mask*255 -> uint8 (no clamp, as test.py:26-27) on the device, already HWC: the D2H copy is
-        # a quarter of the fp32 tensors'
-        rgb, m8 = shared_engine(generated.device.index or 0).quantize_u8(generated.contiguous(), mask.contiguous())
+        # mode='inference' with (x+1)/2*255 and mask*255 -> uint8 (no clamp, as test.py:26-27) fused into the forward's
+        # last kernel, already HWC: nothing but uint8 is written or copied to the host
+        rgb, m8 = model.inference_u8(data_i)
         generated, mask = rgb.cpu().numpy(), m8.cpu().numpy()
         for b in range(generated.shape[0]):
             path = data_i["path"][b]

@@ -136,6 +136,19 @@ def test_quantize_u8_matches_test_py_expression(model):
     assert np.array_equal(m8.cpu().numpy(), want_m)
 
 
+def test_inference_u8_is_the_fused_form_of_quantize_u8(model):
+    """se_inference_u8 (quantisation inside the last kernel) == se_inference followed by se_quantize_u8, bit for bit."""
+    from sketchedit_amd._lib import shared_engine
+    img, sk = synth.make_inputs(2, 64, 72, seed=78)
+    d = {"image": torch.from_numpy(img), "mask": torch.from_numpy(sk)}
+    rgb, m8 = model.inference_u8(dict(d))
+    with torch.no_grad():
+        comp, mask = model(dict(d), mode="inference")
+    rgb2, m82 = shared_engine(0).quantize_u8(comp.contiguous(), mask.contiguous())
+    assert rgb.dtype == torch.uint8 and tuple(rgb.shape) == (2, 64, 72, 3) and tuple(m8.shape) == (2, 64, 72)
+    assert torch.equal(rgb, rgb2) and torch.equal(m8, m82)
+
+
 @pytest.mark.timeout(120)
 def test_serve_process_image_and_dynamic_batching(model):
     """demo.py:39-73 equivalent: arbitrary request size -> multiples of 8 -> forward -> clamp/uint8 -> resize back;

@@ -1,31 +1,50 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): the round's bench line, the rocprofv3 kernel-trace summary and the PMC passes.
-# Everything lands under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards (tools/rocprof_summary.py,
-# tools/pmc_summary.py).   usage: tools/profile_round.sh <tag>
-tag=${1:-r01}
+# Run on the GPU box (gpurun): the round's bench lines with their rocprofv3 evidence.  For each configuration:
+#   <cfg>_bench.json          python bench.py ... (cpu_baseline + parity + live PMC traffic for the headline config)
+#   <cfg>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / avg duration)
+#   <cfg>_pmc_summary.txt     three separate --pmc passes (SQ busy counters, FETCH_SIZE, WRITE_SIZE), tools/pmc_summary.py
+# Everything lands under gpurun_out/<tag>/; copy into profiles/ afterwards.   usage: tools/profile_round.sh <tag> [cfg ...]
+tag=${1:-r02}; shift
+cfgs=${@:-"c2 c3 c5 b1"}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
+Q="--no-cpu-baseline --no-parity --no-traffic"
+profile() {   # name, bench args
+  name=$1; shift
+  cd /tmp
+  B="python $root/bench.py $* --steps 5 --warmup 2 $Q"
+  rocprofv3 --kernel-trace --stats -d $out/${name}_prof -o $name -- $B > $out/${name}_bench_under_rocprof.json 2> $out/${name}_prof.err
+  P="python $root/bench.py $* --steps 1 --warmup 1 $Q"
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+    -d $out/${name}_pmc1 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc1.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${name}_pmc2 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc2.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${name}_pmc3 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc3.err
+  cd $root
+  python tools/rocprof_summary.py $(find $out/${name}_prof -name "*.db" | head -1) $out/${name}_kernel_stats.csv
+  flat=""
+  for d in pmc1 pmc2 pmc3; do
+    dd=$(dirname $(find $out/${name}_$d -name "*counter_collection.csv" | head -1))
+    mkdir -p $out/${name}_${d}_flat; cp $dd/*counter_collection.csv $dd/*kernel_trace.csv $out/${name}_${d}_flat/ 2>/dev/null
+    flat="$flat $out/${name}_${d}_flat"
+  done
+  python tools/pmc_summary.py --json $out/${name}_pmc_traffic.json $flat > $out/${name}_pmc_summary.txt
+  find $out -name "*.db" -delete; rm -rf $out/${name}_pmc1 $out/${name}_pmc2 $out/${name}_pmc3 $out/${name}_pmc?_flat $out/${name}_prof
+}
 cd $root
-python bench.py > $out/bench.json 2> $out/bench.err
-tail -c 600 $out/bench.json
-B="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $out/prof -o $tag -- $B > $out/bench_under_rocprof.json 2> $out/prof.err
-P="python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity"
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-  -d $out/pmc1 --output-format csv -- $P > /dev/null 2> $out/pmc1.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc2 --output-format csv -- $P > /dev/null 2> $out/pmc2.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc3 --output-format csv -- $P > /dev/null 2> $out/pmc3.err
-cd $root
-find $out -name "*.db" -o -name "*counter_collection.csv" | head
-# the databases are large: keep only what the summaries need
-python tools/rocprof_summary.py $(find $out/prof -name "*.db" | head -1) $out/kernel_stats.csv
-for d in pmc1 pmc2 pmc3; do
-  dd=$(dirname $(find $out/$d -name "*counter_collection.csv" | head -1))
-  mkdir -p $out/${d}_flat; cp $dd/*counter_collection.csv $dd/*kernel_trace.csv $out/${d}_flat/ 2>/dev/null
+for cfg in $cfgs; do
+  case $cfg in
+    c2) python bench.py > $out/c2_bench.json 2> $out/c2_bench.err; tail -c 400 $out/c2_bench.json; profile c2 ;;
+    c3) python bench.py --size 512 --batch 8 --steps 30 --no-cpu-baseline > $out/c3_bench.json 2> $out/c3_bench.err; profile c3 --size 512 --batch 8 ;;
+    c5) python bench.py --dtype bf16 --size 512 --batch 16 --steps 30 --no-cpu-baseline > $out/c5_bf16_bench.json 2> $out/c5_bf16_bench.err; profile c5_bf16 --dtype bf16 --size 512 --batch 16 ;;
+    b1) for s in 256 512; do
+          SE_ATT_V1=1 python bench.py --size $s --batch 1 --low-latency off $Q --steps 50 > $out/b1_${s}_round1_kernels.json 2>/dev/null
+          python bench.py --size $s --batch 1 --low-latency off $Q --steps 50 > $out/b1_${s}_default.json 2>/dev/null
+          python bench.py --size $s --batch 1 --low-latency on $Q --steps 50 --layers > $out/b1_${s}_lowlat.json 2>/dev/null
+          python bench.py --size $s --batch 1 --low-latency on --graph $Q --steps 50 > $out/b1_${s}_lowlat_graph.json 2>/dev/null
+        done
+        python bench.py --force-dist $Q --steps 20 > $out/c2_rccl_world1.json 2> $out/c2_rccl_world1.err ;;
+  esac
 done
-python tools/pmc_summary.py --json $out/pmc_traffic.json $out/pmc1_flat $out/pmc2_flat $out/pmc3_flat > $out/pmc_summary.txt
-find $out -name "*.db" -delete; rm -rf $out/pmc1 $out/pmc2 $out/pmc3
-du -sh $out
+du -sh $out; ls $out
