@@ -281,7 +281,9 @@ def main():
                                  "ms_per_step": round(r["total_ms"] / nprof, 4),
                                  "avg_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                                  "executed_tflops": round(r["flops_executed"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["flops_executed"] > 0 else None,
-                                 "algorithmic_tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["flops"] > 0 else None}
+                                 "algorithmic_tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["flops"] > 0 else None,
+                                 # mean workgroups per launch: < 256 leaves CUs of the 256-CU chip without work
+                                 "workgroups_per_launch": r.get("workgroups") or None}
                    for r in rep}
         dom = max(rep, key=lambda r: r["total_ms"])
         executed = dom["flops_executed"] / (dom["total_ms"] * 1e-3) / 1e12
@@ -303,7 +305,11 @@ def main():
                     "forward_mfma_ms": round(mf_ms, 3),
                     "forward_executed_tflops": round(mf_ex / (mf_ms * 1e-3) / 1e12, 3),
                     "forward_executed_frac": round(mf_ex / (mf_ms * 1e-3) / 1e12 / peak, 4),
-                    "forward_algorithmic_tflops": round(mf_al / (mf_ms * 1e-3) / 1e12, 3)}
+                    "forward_algorithmic_tflops": round(mf_al / (mf_ms * 1e-3) / 1e12, 3),
+                    # time-weighted share of the 256 CUs that the MFMA kernels' grids can occupy (one workgroup per CU
+                    # counted as occupied; the batch-1 figure the low-latency mode exists to raise)
+                    "cu_occupancy_by_grid": round(sum(r["total_ms"] * min(1.0, r.get("workgroups", 0) / 256.0) for r in mfma) /
+                                                  max(sum(r["total_ms"] for r in mfma), 1e-9), 3)}
         if world == 1 and not args.no_traffic and not args.force_dist:
             child = ["--steps", "1", "--warmup", "1", "--size", str(S), "--batch", str(B), "--dtype", args.dtype,
                      "--low-latency", args.low_latency, "--no-cpu-baseline", "--no-parity", "--no-traffic"]

@@ -1315,19 +1315,19 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipDeviceSynchronize());
-  double ms[PL_COUNT] = {0}, fl[PL_COUNT] = {0}, by[PL_COUNT] = {0}, ex[PL_COUNT] = {0};
+  double ms[PL_COUNT] = {0}, fl[PL_COUNT] = {0}, by[PL_COUNT] = {0}, ex[PL_COUNT] = {0}, bl[PL_COUNT] = {0};
   long n[PL_COUNT] = {0};
   for (auto& r : c->prof.recs) {
     float t = 0.f;
-    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.label] += t; fl[r.label] += r.flops; ex[r.label] += r.exec_flops; by[r.label] += r.bytes; n[r.label]++; }
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.label] += t; fl[r.label] += r.flops; ex[r.label] += r.exec_flops; by[r.label] += r.bytes; bl[r.label] += (double)r.blocks; n[r.label]++; }
   }
   std::string s = "{\"kernels\": [";
   bool first = true;
   for (int l = 0; l < PL_COUNT; ++l) {
     if (!n[l]) continue;
     char t[384];
-    snprintf(t, sizeof t, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"flops_executed\": %.6e, \"bytes\": %.6e}",
-             first ? "" : ", ", prof_label_name(l), n[l], ms[l], fl[l], ex[l], by[l]);
+    snprintf(t, sizeof t, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"flops_executed\": %.6e, \"bytes\": %.6e, \"workgroups\": %.1f}",
+             first ? "" : ", ", prof_label_name(l), n[l], ms[l], fl[l], ex[l], by[l], bl[l] / (double)n[l]);
     s += t;
     first = false;
   }

@@ -329,8 +329,8 @@ static hipError_t launch_attention_v1(const AttParams& p, hipStream_t st) {
 // (2*R^2*384*2 vs 2*L^2*1536*2 per image), and both GEMMs run the shared 32-k chunk core with b128 fragments
 // (the values are staged transposed, [class][channel][key], so the A operand is k-contiguous).
 // Kernels: prep (xn, key validity, transposed values) -> E GEMM -> row softmax (forms S from E on the fly; one wave per
-// query) -> P~ box sum (one wave per row) -> P~.V GEMM per class (blockIdx.y; the four class workgroups of a pixel tile
-// land on the same XCD -- linear block id % 8 -- and share the P~ tile through its L2).  Deterministic, no atomics.
+// query) -> P~ box sum (one wave per row) -> P~.V GEMM per class (the four class workgroups of a pixel tile are
+// neighbours in one XCD's share of the grid and share the P~ tile through its L2).  Deterministic, no atomics.
 // Summation order differs from the reference's conv (fp32 rounding only): measured <= 2e-6 on `similar`.
 // =====================================================================================================================
 
@@ -414,6 +414,8 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (an image-major 1-D grid with one contiguous range per XCD was measured: no gain in fp32, 0.47 -> 0.67 ms in bf16
+  // where the kernel is bound by the 1 GB of E it writes -- the plain 3-D grid spreads those writes over all XCDs)
   const int b = blockIdx.z;
   const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
   // byte offset of the 2x2 block origin of a row inside THIS image, or an out-of-range offset (hardware zero fill)
@@ -663,8 +665,12 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, cls = blockIdx.y, py = cls >> 1, px = cls & 1;
-  const int t0 = blockIdx.x * PIX;
+  // 1-D grid in (image, pixel tile, class) order, class fastest, every XCD a contiguous range (xcd_tile): the four
+  // class workgroups of a pixel tile run side by side on one XCD and share the P~ tile through its L2
+  const int lb = xcd_tile(blockIdx.x, gridDim.x);
+  const int cls = lb & 3, py = cls >> 1, px = cls & 1;
+  const int nt_ = (p.R + PIX - 1) / PIX;
+  const int b = (lb >> 2) / nt_, t0 = ((lb >> 2) - b * nt_) * PIX;
   const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
   const se_i32x4 rs_P = make_rsrc((const char*)p.E + (size_t)b * p.R * p.Rp * ES, (unsigned)p.R * p.Rp * (unsigned)ES);
   const se_i32x4 rs_V = make_rsrc((const char*)p.xT + ((size_t)b * 4 + cls) * 96 * p.Rp * ES, 96u * p.Rp * (unsigned)ES);
@@ -749,6 +755,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
     dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * (double)p.R * p.R * 384.0);
+    set_launch_grid((long)grid.x * grid.y * grid.z);
     ProfScope ps_(st, PL_ATT_SCORE);
     hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
   }
@@ -775,9 +782,10 @@ static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
     constexpr int LDS = 2 * PT * 64 * 128 + 2 * 96 * 128;
     hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, BF16>, LDS);
     if (e != hipSuccess) return e;
-    dim3 grid((p.R + PT * 64 - 1) / (PT * 64), 4, p.B);
+    dim3 grid(((p.R + PT * 64 - 1) / (PT * 64)) * 4 * p.B);
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * 4.0 * (double)p.R * p.Rp * 96.0);
+    set_launch_grid((long)grid.x * grid.y * grid.z);
     ProfScope ps_(st, PL_ATT_PV);
     hipLaunchKernelGGL((att2_pv_kernel<PT, BF16>), grid, dim3(256), LDS, st, p);
   }

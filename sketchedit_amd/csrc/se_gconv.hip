@@ -31,7 +31,10 @@ namespace se {
 // BF16: activations and weights stored as bf16 (BASELINE config 5): a granule is 8 channels, a chunk 64 k-values, the
 // MFMA v_mfma_f32_16x16x32_bf16 with fp32 accumulators; bias, activation and gate stay fp32, the gated result is
 // rounded to bf16 once (round to nearest even) when it is stored.  Same gather, same LDS image, same tile geometry.
-template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT, bool BF16>
+// STAGES: depth of the LDS ring.  2 = double buffering, one barrier and one vmcnt(0) per chunk: right when a chunk carries
+// microseconds of MFMAs.  > 2 (a power of two): a ring with STAGES - 1 chunks in flight and a COUNTED vmcnt (only the
+// oldest chunk is waited for), available for the small-grid shapes (SE_LL_STAGES=4; measured, not the default).
+template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT, bool BF16, int STAGES>
 __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   constexpr int PIX = PT * 64;
   constexpr int NP = NT * 16;
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   constexpr int NX = PT * 2;                 // X staging pieces (8 rows each) per wave per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
-  char* Wb = smem + 2 * XBYTES;
+  char* Wb = smem + STAGES * XBYTES;
   int2* rowtab = (int2*)smem;   // aliases the X buffers: consumed into registers before the first DMA
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -188,6 +191,40 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (STAGES > 2) {
+    // ---- ring of STAGES slots, AHEAD = STAGES - 1 chunks issued before the first MFMA.  Iteration ch: wait until chunk ch
+    // has landed (every wave has at least PMIN DMA instructions per chunk in flight, so "all but PMIN * (AHEAD - 1)"
+    // covers the oldest chunk), barrier (also: every wave is done reading chunk ch - 1), refill that slot with chunk
+    // ch + AHEAD under the MFMAs of chunk ch.  The DMA instructions are the only vector-memory operations in the loop.
+    constexpr int AHEAD = STAGES - 1;
+    constexpr int PMIN = NX + (NT * 2) / 4;
+    static_assert((STAGES & (STAGES - 1)) == 0 && PMIN * (AHEAD - 1) <= 63, "ring depth");
+    for (int c0 = 0; c0 < AHEAD && c0 < p.nch; ++c0) stage(c0, c0);
+    for (int ch = 0; ch < p.nch; ++ch) {
+      const int buf = ch & (STAGES - 1);
+      if (ch + AHEAD - 1 < p.nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMIN * (AHEAD - 1)) : "memory");
+      else dma_wait_all();
+      __syncthreads();
+      const bool more = ch + AHEAD < p.nch;
+      const int nbuf = (ch + AHEAD) & (STAGES - 1);
+      if (FAST) {
+        if (more) fast_head(ch + AHEAD);
+        constexpr int SLOTS = NT, PER = (NPIECE + SLOTS - 1) / SLOTS;
+        auto hook = [&](int slot) {
+          if (more) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) fast_piece(ch + AHEAD, nbuf, slot * PER + u);
+          }
+        };
+        if (BF16) mfma_chunk16<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, hook);
+        else mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1, hook);
+      } else {
+        if (more) stage(ch + AHEAD, nbuf);
+        if (BF16) mfma_chunk16<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+        else mfma_chunk<NT, PT>(acc, Wb + buf * WBYTES, Xb + buf * XBYTES + w * PT * 2048, off0, off1);
+      }
+    }
+  } else {
   stage(0, 0);
   dma_wait_all();
   __syncthreads();
@@ -214,6 +251,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     }
     dma_wait_all();
     __syncthreads();
+  }
   }
 
   // ---- epilogue: bias, gate, NHWC store (a lane holds 4 consecutive channels of pixel lane&15)
@@ -278,20 +316,21 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   }
 }
 
-template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT, bool BF16>
+template <int NT, int PT, bool MIXED, int WPS, bool FAST, bool SPLIT, bool BF16, int STAGES>
 static hipError_t launch_gconv_f(const GConvParams& p, hipStream_t st, int label) {
   constexpr int PIX = PT * 64;
-  constexpr int LDS = 2 * PIX * 128 + 2 * NT * 16 * 128;
+  constexpr int LDS = STAGES * (PIX * 128 + NT * 16 * 128);
   static_assert(PIX * 8 <= 2 * PIX * 128, "row table aliases the X buffers");
   {
-    hipError_t e = ensure_max_lds((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT, BF16>, LDS);
+    hipError_t e = ensure_max_lds((const void*)gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT, BF16, STAGES>, LDS);
     if (e != hipSuccess) return e;
   }
   const int tiles = (p.total_pix + PIX - 1) / PIX;
   const int grid = p.up2 ? class_tile_grid(tiles) : tiles;
   const int groups = SPLIT ? p.np_full / (NT * 16) : 1;
+  set_launch_grid((long)grid * groups);
   ProfScope ps_(st, label);
-  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT, BF16>), dim3(grid, groups), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((gconv_kernel<NT, PT, MIXED, WPS, FAST, SPLIT, BF16, STAGES>), dim3(grid, groups), dim3(256), LDS, st, p);
   return hipGetLastError();
 }
 
@@ -301,13 +340,13 @@ static bool fast_eligible(const GConvParams& p) {
   return enabled && p.C0g == p.CG && !p.ushift && p.T <= 31 && p.magicKH * p.KW == p.T &&
          (long long)p.B * p.Hin * p.Win * p.C0 * (p.bf16 ? 2 : 4) < (1ll << 31);
 }
-template <int NT, int PT, bool MIXED, int WPS, bool SPLIT = false>
+template <int NT, int PT, bool MIXED, int WPS, bool SPLIT = false, int STAGES = 2>
 static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label) {
   if (p.bf16)
-    return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT, true>(p, st, label)
-                            : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT, true>(p, st, label);
-  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT, false>(p, st, label)
-                          : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT, false>(p, st, label);
+    return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT, true, STAGES>(p, st, label)
+                            : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT, true, STAGES>(p, st, label);
+  return fast_eligible(p) ? launch_gconv_f<NT, PT, MIXED, WPS, true, SPLIT, false, STAGES>(p, st, label)
+                          : launch_gconv_f<NT, PT, MIXED, WPS, false, SPLIT, false, STAGES>(p, st, label);
 }
 
 // (A 3-stage LDS ring for the narrow MIXED shapes -- two chunks of DMA in flight, exact vmcnt waits -- was measured
@@ -330,11 +369,23 @@ hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
   if (p.small_grid) {
     // low-latency shapes: 64-pixel tiles; the wide layers also split their rows over blockIdx.y (one feature tile + its
     // gate tile per workgroup): 6x / 3x more workgroups, each a sixth / third as long
+    // SE_LL_STAGES=4 (developer switch) runs them on the 4-slot ring with a counted vmcnt instead of double buffering.
+    // Measured (1 image): 256x256 1.327 -> 1.313 ms, 512x512 3.75 -> 4.08 ms (48 KB of LDS per workgroup cost more
+    // residency than the deeper prefetch returns; per chunk the ~0.8 us are barrier + issue overhead, not DMA latency).
+    static const int stages = getenv("SE_LL_STAGES") ? atoi(getenv("SE_LL_STAGES")) : 2;
+    if (stages == 2) {
+      switch (cfg) {
+        case GC_N192: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N192);
+        case GC_N96: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N96);
+        case GC_N48: return launch_gconv_t<3, 1, true, 4>(p, st, PL_GCONV_N48);
+        case GC_N24: return launch_gconv_t<2, 1, true, 4>(p, st, PL_GCONV_N24);
+      }
+    }
     switch (cfg) {
-      case GC_N192: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N192);
-      case GC_N96: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N96);
-      case GC_N48: return launch_gconv_t<3, 1, true, 4>(p, st, PL_GCONV_N48);
-      case GC_N24: return launch_gconv_t<2, 1, true, 4>(p, st, PL_GCONV_N24);
+      case GC_N192: return launch_gconv_t<2, 1, false, 3, true, 4>(p, st, PL_GCONV_N192);
+      case GC_N96: return launch_gconv_t<2, 1, false, 3, true, 4>(p, st, PL_GCONV_N96);
+      case GC_N48: return launch_gconv_t<3, 1, true, 3, false, 4>(p, st, PL_GCONV_N48);
+      case GC_N24: return launch_gconv_t<2, 1, true, 3, false, 4>(p, st, PL_GCONV_N24);
     }
     return hipErrorInvalidValue;
   }

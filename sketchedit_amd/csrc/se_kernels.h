@@ -17,7 +17,7 @@ enum ProfLabel { PL_GCONV_N192 = 0, PL_GCONV_N96, PL_GCONV_N48, PL_GCONV_N24, PL
                  PL_ATT_PREP, PL_ATT_SCORE, PL_ATT_SOFTMAX, PL_ATT_BOXSUM, PL_ATT_PV, PL_LAYOUT, PL_COUNT };
 const char* prof_label_name(int l);
 struct Profiler {
-  struct Rec { int label; const char* name; double flops; double exec_flops; double bytes; hipEvent_t a, b; };
+  struct Rec { int label; const char* name; double flops; double exec_flops; double bytes; long blocks; hipEvent_t a, b; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;   // pre-created events (se_profile_enable), handed out two per launch
   size_t used = 0;
@@ -28,6 +28,8 @@ void set_profiler(Profiler* p);          // thread-local; set by the API under t
 // exec_flops = multiply-add FLOPs the kernel's MFMA pipe actually executes (Winograd / sub-pixel / space-to-depth forms
 // execute fewer); < 0: same as flops.  The roofline fraction is computed from exec_flops.
 void set_launch_cost(double flops, double bytes, const char* name = nullptr, double exec_flops = -1.0);
+// workgroups of the NEXT launch (consumed once): lets the report say how much of the 256-CU machine a layer can occupy
+void set_launch_grid(long blocks);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (device, kernel)
 hipError_t ensure_max_lds(const void* func, int bytes);
 

@@ -14,7 +14,9 @@ namespace se {
 static thread_local Profiler* g_prof = nullptr;
 static thread_local double g_next_flops = 0.0, g_next_bytes = 0.0, g_next_exec = 0.0;
 static thread_local const char* g_next_name = nullptr;
+static thread_local long g_next_blocks = 0;
 void set_profiler(Profiler* p) { g_prof = p; }
+void set_launch_grid(long blocks) { g_next_blocks = blocks; }
 void set_launch_cost(double flops, double bytes, const char* name, double exec_flops) {
   g_next_flops = flops; g_next_bytes = bytes; g_next_name = name; g_next_exec = exec_flops < 0.0 ? flops : exec_flops;
 }
@@ -42,11 +44,13 @@ ProfScope::ProfScope(hipStream_t s, int label) : st(s) {
   Profiler* p = g_prof;
   const double fl = g_next_flops, by = g_next_bytes, ex = g_next_exec;
   const char* nm = g_next_name;
+  const long nb = g_next_blocks;
+  g_next_blocks = 0;
   g_next_flops = g_next_bytes = g_next_exec = 0.0;
   g_next_name = nullptr;
   if (!p || !p->on) return;
   Profiler::Rec r;
-  r.label = label; r.name = nm; r.flops = fl; r.exec_flops = ex; r.bytes = by;
+  r.label = label; r.name = nm; r.flops = fl; r.exec_flops = ex; r.bytes = by; r.blocks = nb;
   // events come from a pool created at se_profile_enable(): creating them here cost ~10 us of host time per launch,
   // let the GPU run dry between kernels and inflated the measured durations of short kernels
   if (p->used + 2 > p->pool.size()) return;

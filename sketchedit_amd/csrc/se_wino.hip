@@ -365,6 +365,7 @@ static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const int grid = (p.total_tiles + 63) / 64;
+  set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_N192);
   hipLaunchKernelGGL(wino_kernel<NCHK>, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();

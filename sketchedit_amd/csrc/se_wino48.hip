@@ -332,6 +332,7 @@ hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const int grid = (p.total_tiles + 127) / 128;
+  set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_N96);
   hipLaunchKernelGGL(wino48_kernel, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();

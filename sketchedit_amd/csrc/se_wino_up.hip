@@ -271,6 +271,7 @@ hipError_t launch_winoup(const WinoParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const int grid = class_tile_grid((p.total_tiles + 127) / 128);
+  set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_UP96);
   hipLaunchKernelGGL(winoup_kernel, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
