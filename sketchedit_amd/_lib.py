@@ -15,13 +15,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKETCHEDIT_HIP_LIB points at another build of the same library (developer builds, e.g. tools/wino_trace.py)
 LIB_PATH = os.environ.get("SKETCHEDIT_HIP_LIB") or os.path.join(_HERE, "lib", "libsketchedit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["se_gconv.hip", "se_wino.hip", "se_wino48.hip", "se_wino_up.hip", "se_attention.hip", "se_misc.hip", "se_api.hip"]
+SOURCES = ["se_gconv.hip", "se_rconv16.hip", "se_wino.hip", "se_wino48.hip", "se_wino_up.hip", "se_attention.hip", "se_misc.hip",
+           "se_api.hip"]
 
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
 FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT, FLAG_BF16 = 32, 64, 128, 256   # execution options (include/sketchedit_hip.h)
-# calls of at most this many pixels (two 256x256 images) run in the low-latency mode unless the caller says otherwise
-LOW_LATENCY_MAX_PIXELS = 2 * 256 * 256
+# calls of at most this many pixels (four 256x256 images, one 512x512) run in the low-latency mode unless the caller says
+# otherwise: measured on MI355X, 4 x 256x256 3.59 ms vs 4.55 ms, 1 x 512x512 3.75 ms vs 5.09 ms (low-latency vs default)
+LOW_LATENCY_MAX_PIXELS = 4 * 256 * 256
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",

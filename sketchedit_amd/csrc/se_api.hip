@@ -529,6 +529,23 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
   const LayerDef& d = L.def;
   if (!L.d_w16) return fail(c, "layer %s: no bf16 weight image", d.name);
   if ((C0 + C1) != L.CGp16 * 8) return fail(c, "layer %s: bf16 source channels %d+%d != packed %d", d.name, C0, C1, L.CGp16 * 8);
+  // the dominant shape (96 -> 192, 3x3, stride 1) runs in the raw-tile form when its polyphase sub-images are large
+  // enough to fill 16 x 16 tiles reasonably (se_rconv16.hip); SE_RCONV16=0 keeps it on the gather-GEMM
+  static const bool use_rconv = !(getenv("SE_RCONV16") && atoi(getenv("SE_RCONV16")) == 0);
+  if (use_rconv && !c->low_latency && d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && !src1 && C0 == 96 &&
+      (Hin % d.rate) == 0 && (Win % d.rate) == 0 && Hin / d.rate >= 12 && Win / d.rate >= 12 && L.nch16 == 14 &&
+      (long long)B * Hin * Win * 192 < (1ll << 31)) {
+    RConvParams rp;
+    memset(&rp, 0, sizeof rp);
+    rp.src = src0; rp.wpk = L.d_w16; rp.bias = L.d_b; rp.dst = dst;
+    rp.B = B; rp.h = Hin; rp.w = Win; rp.d = d.rate; rp.hs = Hin / d.rate; rp.ws = Win / d.rate;
+    rp.ty = (rp.hs + 15) / 16; rp.tx = (rp.ws + 15) / 16;
+    rp.act = d.act; rp.xcd = xcd_remap_enabled();
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 2.0 * 2.0 * (double)B * Hin * Win * 96, d.name, 2.0 * (double)B * Hin * Win * 192.0 * 896.0);
+    HIPCHK(c, launch_rconv16(rp, c->st));
+    return 0;
+  }
   GConvParams p;
   memset(&p, 0, sizeof p);
   p.bf16 = 1;

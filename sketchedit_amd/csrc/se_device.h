@@ -165,28 +165,37 @@ DEVFN unsigned pack_bf16x2(float lo, float hi) {
 DEVFN float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 DEVFN float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-// One 64-k chunk of bf16 operands: same tile addressing as mfma_chunk, one MFMA per (k-half, channel tile, pixel tile)
+// One 64-k chunk of bf16 operands: same tile addressing as mfma_chunk, one MFMA per (k-half, channel tile, pixel tile).
+// A bf16 MFMA is short (~17 cycles per SIMD), so an A fragment feeds only PT * 17 cycles of matrix work: with the fp32
+// core's one-fragment look-ahead the LDS latency (~100+ cycles under load) was exposed on every fragment and the pipe
+// sat at ~40 cycles per MFMA.  Here a window of DEPTH fragments is kept in flight across the 2 * NT (k-half, tile)
+// steps of the chunk.
 template <int NT, int PT, typename Hook = NoHook>
 DEVFN void mfma_chunk16(f32x4 (&acc)[NT][PT], const char* __restrict__ Wt, const char* __restrict__ Xt, int off0,
                         int off1, Hook hook = Hook()) {
+  constexpr int NU = 2 * NT, DEPTH = NU < 6 ? NU : 6;
   bf16x8 xb[2][PT];
 #pragma unroll
   for (int half = 0; half < 2; ++half)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) xb[half][pt] = *(const bf16x8*)(Xt + pt * 2048 + (half ? off1 : off0));
-  bf16x8 wn = *(const bf16x8*)(Wt + off0);
+  bf16x8 wq[DEPTH];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int u = 0; u < DEPTH; ++u) wq[u] = *(const bf16x8*)(Wt + (u % NT) * 2048 + (u / NT ? off1 : off0));
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bf16x8 wa = wn;
-      if (nt + 1 < NT) wn = *(const bf16x8*)(Wt + (nt + 1) * 2048 + (half ? off1 : off0));
-      else if (half == 0) wn = *(const bf16x8*)(Wt + off1);
+  for (int u = 0; u < NU; ++u) {
+    const int half = u / NT, nt = u % NT;
+    const bf16x8 wa = wq[u % DEPTH];
+    if (u + DEPTH < NU) wq[u % DEPTH] = *(const bf16x8*)(Wt + ((u + DEPTH) % NT) * 2048 + ((u + DEPTH) / NT ? off1 : off0));
+    // pin the order: left to itself hipcc sinks every fragment read to just in front of its two MFMAs and waits
+    // lgkmcnt(0) there (read - wait - 2 MFMAs, ~40 cycles per MFMA); with the order fixed it emits counted waits
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
-        acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[half][pt], acc[nt][pt], 0, 0, 0);
-      hook(half * NT + nt);
-    }
+    for (int pt = 0; pt < PT; ++pt)
+      acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[half][pt], acc[nt][pt], 0, 0, 0);
+    hook(u);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -115,6 +115,22 @@ hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
 hipError_t launch_winoup(const WinoParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
+// bf16 raw-tile form of the 3x3 stride-1 gated conv 96 -> 192 (se_rconv16.hip)
+// ---------------------------------------------------------------------------------------------
+struct RConvParams {
+  const void* src;     // bf16 NHWC [B][h][w][96]
+  const void* wpk;     // bf16 image of pack_layer16: [14 chunks][192 rows][64 k]
+  const float* bias;   // [192] packed-row order (features, then gates)
+  void* dst;           // bf16 NHWC [B][h][w][96]
+  int B, h, w, d;      // dilation d; h % d == 0 and w % d == 0
+  int hs, ws;          // polyphase sub-image size h/d x w/d
+  int ty, tx;          // 16 x 16 tiles per sub-image
+  int act;             // 0 ELU, 1 ReLU
+  int xcd;             // 1: XCD-aware tile order
+};
+hipError_t launch_rconv16(const RConvParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 conv 12 -> {1,3} raw output + fused tanh/sigmoid/composite (final layer of each decoder)
 // ---------------------------------------------------------------------------------------------
 struct SmallConvParams {

@@ -1,0 +1,193 @@
+// bf16 gated convolution 96 -> 192, 3x3, stride 1, any dilation -- "raw tile" form (BASELINE config 5).
+//
+// The gather-GEMM of se_gconv.hip stages an im2col image: every input pixel enters LDS once per tap (9x) and the
+// [192][64-k] weight tile once per 128 output pixels.  On the bf16 pipe that kernel is bound by the LDS fill (measured:
+// ~19 B/clk/CU of LDS-DMA, MFMA pipe 36 % busy), so this kernel cuts the bytes that are staged:
+//   * the input tile of a 16 x 16 block of outputs (18 x 18 pixels with the halo, all 96 channels, 61 KB) is DMA'd into
+//     LDS ONCE in its natural pixel-major layout, and the MFMA B fragments of all 9 taps are read straight from it -- a
+//     tap is an address offset, nothing is re-staged;
+//   * one workgroup = 8 waves = 256 output pixels, so a weight tile serves twice as many pixels.
+// 407 KB staged per 256 outputs instead of 1120 KB.  Weights: the very image pack_layer16 builds for the gather-GEMM
+// ([14 chunks][192 rows][64 k], k = tap * 96 + channel): a 32-k MFMA step never straddles a tap because 96 = 3 * 32.
+//
+// Dilation d: the conv on the d x d polyphase sub-images (pixel (sy, sx) of phase (py, px) = image pixel
+// (sy d + py, sx d + px)); a tile is 16 x 16 pixels of ONE sub-image, its taps are +-1 in sub-image coordinates.
+//
+// LDS layout of the raw tile: [18 rows][18 columns][12 granules of 8 channels], 192 B per pixel, no padding; within
+// each group of 4 granules (one 32-k step) the granule index is XORed with 2 for the pixel columns whose bit 2 is set.
+// With that, the 16 lanes of every ds_read_b128 lane group (16 pixel columns x 2 adjacent granules, gfx950's
+// non-contiguous groups) hit 16 distinct 16-byte slots of the 256-byte bank row for all three column shifts of the taps
+// (exhaustive check: tools/lds_layout_search.py).  The swizzle is applied on the SOURCE side of the LDS-DMA (which lane
+// fetches which granule); the destination stays lane-linear.
+//
+// Reference semantics: gen_conv, /root/reference/models/networks/utils.py:9-33 (zero padding = rate, ELU / ReLU on the
+// first 96 channels times sigmoid of the last 96); rounding points of the bf16 mode: oracle/sketchedit_oracle.py.
+#include "se_device.h"
+
+#include <cstdlib>
+
+namespace se {
+
+__global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
+  constexpr int TS = 16, RS = TS + 2;                 // tile side, raw (halo) tile side
+  constexpr int ROWB = RS * 192;                      // bytes per raw tile row
+  constexpr int NDMA = (RS * RS * 12 + 63) / 64;      // 61 LDS-DMA instructions fill the raw tile
+  constexpr int RAWB = NDMA * 1024;
+  constexpr int WB = 192 * 128;
+  constexpr int NCH = 14, NSTEP = 27;                 // 64-k weight chunks, 32-k MFMA steps (9 taps x 3)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Raw = smem;
+  char* Wb = smem + RAWB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup -> (image, phase, tile); tiles of one sub-image are neighbours in one XCD's share of the grid
+  const int lb = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tpi = p.ty * p.tx, per_img = p.d * p.d * tpi;
+  const int b = lb / per_img, r1 = lb - b * per_img;
+  const int ph = r1 / tpi, t = r1 - ph * tpi;
+  const int py = ph / p.d, px = ph - py * p.d;
+  const int ty0 = (t / p.tx) * TS, tx0 = (t % p.tx) * TS;
+
+  const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.h * p.w * 192u);
+  const unsigned lds_raw = lds_addr_of(Raw), lds_w = lds_addr_of(Wb);
+  auto dma_w = [&](int ch, int buf, int j) {      // piece j (0..2) of this wave's share of weight chunk ch
+    const int rbk = j * 8 + w;
+    glds16_s((const float*)p.wpk + (size_t)ch * 192 * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WB + rbk * 1024);
+  };
+  // ---- prologue: the first weight chunk and the raw tile
+  dma_w(0, 0, 0); dma_w(0, 0, 1); dma_w(0, 0, 2);
+#pragma unroll
+  for (int i0 = 0; i0 < (NDMA + 7) / 8; ++i0) {
+    const int i = i0 * 8 + w;
+    if (i < NDMA) {
+      const int q = i * 64 + lane;                   // granule slot of the raw tile
+      const int pix = q / 12, gs = q - pix * 12;
+      const int row = pix / RS, c = pix - row * RS;
+      const int gl = gs ^ (((c >> 2) & 1) << 1);     // stored slot gs holds logical granule gl (see the layout note)
+      const int sy = ty0 - 1 + row, sx = tx0 - 1 + c;
+      const bool ok = q < RS * RS * 12 && (unsigned)sy < (unsigned)p.hs && (unsigned)sx < (unsigned)p.ws;
+      const unsigned off = (unsigned)((b * p.h + sy * p.d + py) * p.w + sx * p.d + px) * 192u + (unsigned)gl * 16u;
+      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);
+    }
+  }
+  // per-lane fragment addressing.  B (pixels): lane (j = lane & 15, g = lane >> 4) reads granule g of the step's 4 for
+  // pixel column j + kx; A (weights): the tile addressing of mfma_chunk16.
+  int bk[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int c = (lane & 15) + kx;
+    bk[kx] = c * 192 + (((lane >> 4) ^ (((c >> 2) & 1) << 1)) << 4);
+  }
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+
+  f32x4 acc[12][2];
+#pragma unroll
+  for (int nt = 0; nt < 12; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_wait_all();
+  __syncthreads();
+  // A bf16 MFMA is ~17 cycles per SIMD and an A (weight) fragment feeds only two of them, so fragments are kept DEPTH
+  // deep in flight (a one-fragment look-ahead exposed the LDS latency on every fragment: ~42 cycles per MFMA).  The B
+  // (pixel) fragments come from the raw tile, which never changes: those of the next chunk are read during this one.
+  constexpr int DEPTH = 6;
+  auto bfrag = [&](int s, int pt) -> bf16x8 {          // s = 32-k step (compile-time): tap s / 3, channels 32 (s % 3) ..
+    const int tap = s / 3, kk = s - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+    return *(const bf16x8*)(Raw + (2 * w + pt + ky) * ROWB + bk[kx] + kk * 64);
+  };
+  bf16x8 xb[2][2], xn[2][2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) xb[half][pt] = bfrag(half, pt);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {      // fully unrolled: taps, k-steps, buffers and register rotation are compile-time
+    const int buf = ch & 1;
+    const char* Wt = Wb + buf * WB;
+    const int nu = (ch * 2 + 1 < NSTEP) ? 24 : 12;     // the second half of the last chunk is K padding
+    bf16x8 wq[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) wq[u] = *(const bf16x8*)(Wt + (u % 12) * 2048 + (u / 12 ? off1 : off0));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 24; ++u) {
+      if (u >= nu) continue;
+      const int half = u / 12, nt = u % 12;
+      const bf16x8 wa = wq[u % DEPTH];
+      if (u + DEPTH < nu) wq[u % DEPTH] = *(const bf16x8*)(Wt + ((u + DEPTH) % 12) * 2048 + ((u + DEPTH) / 12 ? off1 : off0));
+      // the next chunk's pixel fragments (the raw tile never changes)
+      if (u >= 4 && u < 8 && ch + 1 < NCH) {
+        const int h2 = (u - 4) >> 1, pt2 = (u - 4) & 1, s2 = (ch + 1) * 2 + h2;
+        if (s2 < NSTEP) xn[h2][pt2] = bfrag(s2, pt2);
+      }
+      // pin the order (hipcc would sink every read to just in front of its MFMAs and wait lgkmcnt(0) there)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[half][pt], acc[nt][pt], 0, 0, 0);
+      // the next chunk's weight DMA, one piece per MFMA group (a burst stalls the wave)
+      if (u < 3 && ch + 1 < NCH) dma_w(ch + 1, buf ^ 1, u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) xb[half][pt] = xn[half][pt];
+    dma_wait_all();
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, gate, bf16 NHWC store.  A lane holds 4 consecutive channels (8 bytes) of pixel column lane & 15:
+  // stored directly, every instruction scatters 8-byte pieces over 64 different 192-byte pixels and the store tail cost
+  // 24 % of the kernel (measured by ablation).  The gated tile is therefore transposed through LDS (the raw tile's room,
+  // free after the last barrier; 208 bytes per pixel keep the 16-byte reads aligned) and leaves as full 16-byte pieces,
+  // 1 KB contiguous per wave instruction.
+  constexpr int OPX = 208;
+  const int q = lane >> 4, jx = lane & 15;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    char* o = Raw + ((2 * w + pt) * 16 + jx) * OPX;
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+      const int c0 = nt * 16 + q * 4;
+      const f32x4 bf = *(const f32x4*)(p.bias + c0);
+      const f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
+      float ov[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float f = acc[nt][pt][r] + bf[r];
+        const float g = acc[nt + 6][pt][r] + bg[r];
+        ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
+      }
+      *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {                  // 256 pixels x 12 pieces of 16 bytes = 6 per thread
+    const int piece = it * 512 + tid;
+    const int pix = piece / 12, part = piece - pix * 12;
+    const int sy = ty0 + (pix >> 4), sx = tx0 + (pix & 15);
+    if (sy < p.hs && sx < p.ws)
+      *(uint4*)((char*)p.dst + ((size_t)(b * p.h + sy * p.d + py) * p.w + sx * p.d + px) * 192 + part * 16) =
+          *(const uint4*)(Raw + pix * OPX + part * 16);
+  }
+}
+
+hipError_t launch_rconv16(const RConvParams& p, hipStream_t st) {
+  constexpr int LDS = 61 * 1024 + 2 * 192 * 128;     // raw tile 61 KB + weight double buffer 48 KB
+  {
+    hipError_t e = ensure_max_lds((const void*)rconv16_kernel, LDS);
+    if (e != hipSuccess) return e;
+  }
+  const int grid = p.B * p.d * p.d * p.ty * p.tx;
+  set_launch_grid(grid);
+  ProfScope ps_(st, PL_GCONV_N192);
+  hipLaunchKernelGGL(rconv16_kernel, dim3(grid), dim3(512), LDS, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace se

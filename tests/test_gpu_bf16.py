@@ -83,6 +83,24 @@ def test_op_gated_conv_bf16(eng, shape, ll):
         _layer_close(y, O.gated_conv(tx, tw, tb, s, r, "elu", BF))
 
 
+RCONV = [(1, 16, 16, "elu"), (1, 32, 48, "relu"), (1, 22, 18, "elu"), (2, 24, 32, "elu"), (4, 48, 64, "elu"), (2, 36, 28, "elu"),
+         (1, 12, 12, "elu"), (8, 128, 96, "elu")]
+
+
+@pytest.mark.parametrize("case", RCONV, ids=["d%d-%dx%d-%s" % c for c in RCONV])
+def test_op_rconv16_raw_tile_bf16(eng, case):
+    """96 -> 192 3x3 stride 1 in the raw-tile form (se_rconv16.hip): exact and ragged 16x16 tiles, the image borders (zero
+    padding through the buffer range check), dilations through the polyphase sub-images."""
+    from oracle import sketchedit_oracle as O
+    d, H, W, act = case
+    a = 1.5 / np.sqrt(96 * 9)
+    w = synth.uniform(41, "rc.w%s" % (case,), (192, 96, 3, 3), -a, a)
+    b = synth.uniform(41, "rc.b%s" % (case,), (192,), -0.3, 0.3)
+    x = synth.uniform(41, "rc.x%s" % (case,), (2, 96, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act, bf16=True)
+    _layer_close(y, O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act, BF))
+
+
 @pytest.mark.parametrize("kind", ["tensor", "vector"])
 def test_op_two_source_conv_bf16(eng, kind):
     from oracle import sketchedit_oracle as O
