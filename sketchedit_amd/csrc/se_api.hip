@@ -1161,16 +1161,17 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
   std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 0;
   // every flag combination that changes the allocation sequence (a first-fit arena does not peak monotonically):
-  // attention on/off, 4- or 8-channel style input, in-line or concurrent branches
+  // attention on/off, 4- or 8-channel style input, in-line or concurrent branches, fp32 or bf16 activations
   size_t peak = 0;
   for (int cam = 0; cam < 2; ++cam)
     for (int joint = 0; joint < 2; ++joint)
-      for (int ll = 0; ll < 2; ++ll) {
-        const int flags = (cam ? SE_FLAG_USE_CAM : 0) | (joint ? SE_FLAG_JOINT_TRAIN_INP : 0) | (ll ? SE_FLAG_LOW_LATENCY : 0) |
-                          SE_FLAG_POOL_MAX;
-        const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, true);
-        if (pk.main + pk.side > peak) peak = pk.main + pk.side;
-      }
+      for (int ll = 0; ll < 2; ++ll)
+        for (int bf = 0; bf < 2; ++bf) {      // (bf16 activations are smaller, but its attention scratch need not be)
+          const int flags = (cam ? SE_FLAG_USE_CAM : 0) | (joint ? SE_FLAG_JOINT_TRAIN_INP : 0) | (ll ? SE_FLAG_LOW_LATENCY : 0) |
+                            (bf ? SE_FLAG_BF16 : 0) | SE_FLAG_POOL_MAX;
+          const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, true);
+          if (pk.main + pk.side > peak) peak = pk.main + pk.side;
+        }
   return peak + 2 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes
 }
 
