@@ -521,6 +521,48 @@ int pack_net_layer(se_ctx* c, Layer& L) {
   return pack_layer(c, L, m);
 }
 
+// ---- narrow layers in raw-tile form (se_rtile.hip): returns 0 and sets *done when the layer was launched there ------
+int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, const float* src1, float* dst, int B, int Hin, int Win,
+              int Ho, int Wo, int pad, bool* done) {
+  *done = false;
+  const LayerDef& d = L.def;
+  static const bool enabled = !(getenv("SE_RTILE") && atoi(getenv("SE_RTILE")) == 0);
+  if (!enabled || c->low_latency || src1 || d.stride != 1 || d.rate != 1 || (L.cfg != GC_N48 && L.cfg != GC_N24)) return 0;
+  const int es = bf ? 2 : 4, gran = bf ? 8 : 4;
+  const int CG = bf ? L.CGp16 : L.CGp, nch = bf ? L.nch16 : L.nch;
+  const float* wimg = bf ? L.d_w16 : L.d_w;
+  if (!wimg || C0 != CG * gran) return 0;
+  const int KW = d.up ? 2 : d.k, KH = KW;
+  RTileParams p;
+  memset(&p, 0, sizeof p);
+  p.RH = 8 + KH - 1; p.RW = 16 + KW - 1;
+  p.raw_bytes = (p.RH * p.RW * C0 * es + 1023) & ~1023;
+  if (p.raw_bytes + nch * L.NP * 128 > 80 * 1024) return 0;                 // two workgroups per CU or not at all
+  if ((long long)B * Hin * Win * C0 * es >= (1ll << 31)) return 0;
+  p.src = src0; p.wpk = wimg; p.bias = L.d_b; p.dst = dst;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.C = C0; p.CG = CG; p.T = L.T; p.KW = KW;
+  p.magicCG = (65536 + CG - 1) / CG; p.magicKW = 256 / KW + 1;
+  for (int gi = 0; gi < nch * 8 + 8; ++gi)
+    if (((gi * p.magicCG) >> 16) != gi / CG) return 0;
+  for (int t = 0; t <= L.T + 8; ++t)
+    if (((t * p.magicKW) >> 8) != t / KW) return 0;
+  p.pad = pad; p.up2 = d.up ? 1 : 0; p.OH = Ho; p.OW = Wo;
+  p.G = bf ? (L.G + 7) & ~7 : L.G;
+  p.nch = nch; p.NP = L.NP;
+  udiv_magic_host((unsigned)(C0 * es / 16), &p.div_cg_m, &p.div_cg_l);
+  udiv_magic_host((unsigned)p.RW, &p.div_rw_m, &p.div_rw_l);
+  p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
+  p.act = d.act; p.bf16 = bf ? 1 : 0; p.xcd = xcd_remap_enabled();
+  {
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k;
+    const double exec = 2.0 * (double)B * Hin * Win * (d.up ? 4.0 : 1.0) * L.NP * (nch * (bf ? 64.0 : 32.0));
+    set_launch_cost(alg, (double)es * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name, exec);
+  }
+  HIPCHK(c, launch_rtile(p, c->st));
+  *done = true;
+  return 0;
+}
+
 // ---- bf16 mode: every gated conv is the direct gather-GEMM on v_mfma_f32_16x16x32_bf16 (se_gconv.hip, BF16) -----------
 // (The Winograd transforms would have to run in fp32 on bf16 data and round the transformed tiles again; at 16x the
 // MFMA rate the layers are bound by the LDS fill, not by multiply-adds, so there is nothing for them to buy.)
@@ -545,6 +587,11 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
     set_launch_cost(alg, 2.0 * 2.0 * (double)B * Hin * Win * 96, d.name, 2.0 * (double)B * Hin * Win * 192.0 * 896.0);
     HIPCHK(c, launch_rconv16(rp, c->st));
     return 0;
+  }
+  {
+    bool done = false;
+    if (try_rtile(c, L, true, src0, C0, src1, dst, B, Hin, Win, Ho, Wo, pad, &done)) return 1;
+    if (done) return 0;
   }
   GConvParams p;
   memset(&p, 0, sizeof p);
@@ -660,6 +707,11 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
                     alg * 9.0 / 36.0);                       // F(2x2,2x2) on the sub-pixel classes: 9 of 36 products
     HIPCHK(c, launch_winoup(wp, c->st));
     return 0;
+  }
+  {
+    bool done = false;
+    if (try_rtile(c, L, false, src0, C0, src1, dst, B, Hin, Win, Ho, Wo, pad, &done)) return 1;
+    if (done) return 0;
   }
   GConvParams p;
   memset(&p, 0, sizeof p);

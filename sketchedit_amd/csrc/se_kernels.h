@@ -131,6 +131,32 @@ struct RConvParams {
 hipError_t launch_rconv16(const RConvParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
+// Raw-tile form of the narrow (MIXED-row) stride-1 gated convs, fp32 and bf16 (se_rtile.hip)
+// ---------------------------------------------------------------------------------------------
+struct RTileParams {
+  const float* src;    // NHWC [B][Hin][Win][C] (fp32, or bf16 when `bf16`)
+  const float* wpk;    // packed weight image of pack_layer / pack_layer16 ([class][chunk][NP rows][128 bytes])
+  const float* bias;   // [NP] packed-row order
+  float* dst;          // NHWC [B][OH][OW][G]
+  int B, Hin, Win;     // source grid (= output grid; for up2 the output grid is 2x)
+  int C;               // elements per source pixel (whole granules)
+  int CG;              // granules per tap
+  int T, KW;           // taps, taps per kernel row (up2: 4, 2)
+  int magicCG, magicKW;
+  int pad;             // top / left zero padding (k / 2); up2: 1 - class parity
+  int up2, OH, OW;
+  int G;               // stored output channels (row stride of dst)
+  int nch, NP;         // 32-k (fp32) / 64-k (bf16) chunks, packed rows (48 or 32)
+  int RH, RW;          // raw tile: 8 + KH - 1 rows, 16 + KW - 1 columns
+  int raw_bytes;       // RH * RW * C * element size, rounded up to 1 KB
+  unsigned div_cg_m, div_rw_m;   // udiv_magic numbers for (granules per pixel) and RW
+  int div_cg_l, div_rw_l;
+  int ty, tx;          // 8 x 16 tiles per image
+  int act, bf16, xcd;
+};
+hipError_t launch_rtile(const RTileParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 conv 12 -> {1,3} raw output + fused tanh/sigmoid/composite (final layer of each decoder)
 // ---------------------------------------------------------------------------------------------
 struct SmallConvParams {

@@ -1,0 +1,172 @@
+// Narrow gated convolutions (24 or 12 gated output channels: the 5x5 first layers, the 48 -> 48 gen_deconv, the 24 -> 24
+// layers -- all at full or half image resolution) in "raw tile" form, fp32 and bf16.
+//
+// On these layers the gather-GEMM of se_gconv.hip is bound by the LDS fill, not by the MFMA pipe: its im2col image
+// stages every input pixel once per tap (9x, 25x for the 5x5 layers) -- 16 KB of pixels + 6 KB of weights per 32-k chunk
+// and 128 outputs against 1536 cycles of fp32 MFMAs, i.e. 28.6 B/clk for two resident workgroups where the CU's LDS-DMA
+// sustains about 19 B/clk: the pipe sits at 65 % (profiles/r02_c2_pmc_summary.txt).  Here
+//   * the input tile of an 8 x 16 block of outputs (with its halo, every channel) is DMA'd into LDS ONCE, pixel-major,
+//     and the B fragments of every tap are read straight from it (a tap is an address offset);
+//   * the layer's WHOLE packed weight image (25 - 43 KB for these shapes) is resident in LDS, loaded in the prologue:
+//     the k loop has no staging, no vmcnt wait and no barrier at all.
+// 28 - 66 KB staged per 128 outputs instead of 88 - 170 KB, and two workgroups per CU overlap one's prologue / epilogue
+// with the other's MFMAs.  The weight image, the row order (MIXED: 8 features + their 8 gates per 16-row tile), the k
+// order, the MFMA sequence and the epilogue are those of gconv_kernel, so the results are bit-identical to it.
+//
+// gen_deconv (nearest x2 + 3x3) runs in its sub-pixel form: class (py,px) is a 2x2 conv on the source grid whose raw tile
+// is 9 x 17 source pixels; the four class workgroups of a tile are neighbours in one XCD's dispatch sequence (class_tile).
+// Reference semantics: gen_conv / gen_deconv, /root/reference/models/networks/utils.py:9-51.
+#include "se_device.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace se {
+
+template <int NT, bool BF16>
+__global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
+  constexpr int ES = BF16 ? 2 : 4;           // bytes per stored element
+  constexpr int PT = 2;                      // a wave = 2 rows of 16 output pixels
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Raw = smem;
+  char* Wres = smem + p.raw_bytes;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.B * p.ty * p.tx;
+  int tile, cls = 0;
+  if (p.up2) {
+    if (!class_tile((int)blockIdx.x, ntiles, p.xcd, tile, cls)) return;
+  } else {
+    tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  }
+  const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
+  const int ty0 = (t2 / p.tx) * 8, tx0 = (t2 % p.tx) * 16;
+  const int py = cls >> 1, px = cls & 1;
+  const int pady = p.up2 ? 1 - py : p.pad, padx = p.up2 ? 1 - px : p.pad;
+  const int pixb = p.C * ES;                 // bytes per source pixel
+  const int cgp = pixb >> 4;                 // 16-byte granules per source pixel
+
+  // ---- prologue: the whole weight image of this layer (class) and the raw tile, by LDS-DMA
+  const unsigned lds_raw = lds_addr_of(Raw), lds_w = lds_addr_of(Wres);
+  {
+    const float* wsrc = p.wpk + (size_t)cls * p.nch * p.NP * 32;
+    const int npieces = p.nch * p.NP / 8;    // 1 KB pieces (8 rows of 128 bytes)
+    for (int i = w; i < npieces; i += 4) glds16_s(wsrc + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
+    const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.Hin * p.Win * (unsigned)pixb);
+    const int slots = p.RH * p.RW * cgp;
+    for (int i = w; i * 64 < slots; i += 4) {
+      const int q = i * 64 + lane;
+      const int pix = (int)udiv_magic((unsigned)q, p.div_cg_m, p.div_cg_l), gs = q - pix * cgp;
+      const int row = (int)udiv_magic((unsigned)pix, p.div_rw_m, p.div_rw_l), c = pix - row * p.RW;
+      const int sy = ty0 - pady + row, sx = tx0 - padx + c;
+      const bool ok = q < slots && (unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win;
+      const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)gs * 16u;
+      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);      // outside the image: hardware zero fill
+    }
+  }
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const int jx = lane & 15, g4 = lane >> 4;
+  const int rowb = p.RW * pixb;                                          // bytes per raw tile row
+  const int xbase = ((2 * w) * p.RW + jx) * pixb;                        // this lane's pixel of the wave's first row
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_wait_all();
+  __syncthreads();
+
+  // ---- k loop: no staging, no barrier.  Granule gi of the flattened (tap, channel group) axis -> raw tile offset.
+  auto tap_off = [&](int gi) -> int {
+    int tap = __umul24(gi, p.magicCG) >> 16;
+    const int cg = gi - __umul24(tap, p.CG);
+    tap = min(tap, p.T - 1);                                             // K padding: zero weights, any valid address
+    const int ky = __umul24(tap, p.magicKW) >> 8, kx = tap - __umul24(ky, p.KW);
+    return __mul24(ky, rowb) + __mul24(kx, pixb) + (cg << 4);
+  };
+  // No register software pipeline: a ping-pong version (fragments of chunk c + 1 read behind the MFMAs of chunk c,
+  // pinned with sched_barriers) measured the same in fp32 and 6 % slower in bf16 -- the second resident workgroup
+  // already covers the LDS latency, and the loop is MFMA-bound (fp32) or LDS-read-bound (bf16) either way.
+  typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
+  for (int ch = 0; ch < p.nch; ++ch) {
+    frag_t wq[2 * NT], xb[2][PT];
+#pragma unroll
+    for (int u = 0; u < 2 * NT; ++u)
+      wq[u] = *(const frag_t*)(Wres + ch * (p.NP * 128) + (u % NT) * 2048 + (u / NT ? off1 : off0));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int xo = xbase + tap_off(ch * 8 + half * 4 + g4);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) xb[half][pt] = *(const frag_t*)(Raw + xo + pt * rowb);
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * NT; ++u) {
+      const int half = u / NT, nt = u % NT;
+      if constexpr (BF16) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[u], xb[half][pt], acc[nt][pt], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt)
+            acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][r], xb[half][pt][r], acc[nt][pt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue (gconv_kernel, MIXED): tile rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32); two
+  // v_permlane32_swap per quad hand every lane two complete (feature, gate) pairs
+  const int q = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
+    const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int yy = ty0 + 2 * w + pt, xx = tx0 + jx;
+      const f32x4 v = acc[nt][pt] + bq;
+      const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+      const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+      const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+      float2 o;
+      o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
+      o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+      if (c0 < p.G && yy < p.Hin && xx < p.Win) {
+        const int oy = p.up2 ? 2 * yy + py : yy, ox = p.up2 ? 2 * xx + px : xx;
+        const size_t at = ((size_t)(b * p.OH + oy) * p.OW + ox) * p.G + c0;
+        if (BF16) *(unsigned*)((char*)p.dst + at * 2) = pack_bf16x2(o.x, o.y);
+        else *(float2*)(p.dst + at) = o;
+      }
+    }
+  }
+}
+
+template <int NT, bool BF16>
+static hipError_t launch_rtile_t(const RTileParams& p, hipStream_t st, int label) {
+  const int lds = p.raw_bytes + p.nch * p.NP * 128;
+  {
+    hipError_t e = ensure_max_lds((const void*)rtile_kernel<NT, BF16>, 80 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  const int tiles = p.B * p.ty * p.tx;
+  const int grid = p.up2 ? class_tile_grid(tiles) : tiles;
+  set_launch_grid(grid);
+  ProfScope ps_(st, label);
+  hipLaunchKernelGGL((rtile_kernel<NT, BF16>), dim3(grid), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_rtile(const RTileParams& p, hipStream_t st) {
+  if (p.NP == 48) return p.bf16 ? launch_rtile_t<3, true>(p, st, PL_GCONV_N48) : launch_rtile_t<3, false>(p, st, PL_GCONV_N48);
+  if (p.NP == 32) return p.bf16 ? launch_rtile_t<2, true>(p, st, PL_GCONV_N24) : launch_rtile_t<2, false>(p, st, PL_GCONV_N24);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace se
