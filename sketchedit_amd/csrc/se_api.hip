@@ -1010,7 +1010,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
     valid = P.alloc_raw((size_t)B * Rp);
     xT = P.alloc_raw(bf ? (size_t)B * 4 * 96 * Rp / 2 : (size_t)B * 4 * 96 * Rp);
     S = P.alloc_raw((size_t)B * R * Rp);       // E (fp32), then P~ (fp32, or bf16 in its front half)
-    S2 = P.alloc_raw((size_t)B * R * Rp);      // P
+    S2 = P.alloc_raw(bf ? (size_t)B * R * Rp / 2 : (size_t)B * R * Rp);      // P (fp32 / bf16)
   } else {
     valid = P.alloc_raw((size_t)B * Lp);
     S = P.alloc_raw((size_t)B * L * Lp);

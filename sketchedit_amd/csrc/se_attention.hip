@@ -500,6 +500,10 @@ static inline long tile_order_count(int B, int ny, int nx) { return (long)B * ((
 
 // One wave per query i: S[j] = scale * valid[j] * sum_d E[i+d][j+d] (splitcam.py:69,90,104), softmax over the keys
 // (:105); written in class-grid indexing, zero at the grid positions that are not keys and in the pad columns.
+// P is fp32, or bf16 in bf16 mode (the oracle rounds P before the reconstruction, sketchedit_oracle.py
+// attention_reconstruct).  fp32: the row of P is the scratch for the scores; bf16: the scores are recomputed in each
+// of the three sweeps (this kernel only runs for rows that do not fit the register form: feature maps above 128 x 128).
+template <bool BF16>
 __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
   int b, iy, ix;
@@ -511,13 +515,15 @@ __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
   const float* E3 = E2 + p.Rp;                                // (iy+1, ix+1)
   const float* vr = p.validR + (size_t)b * p.Rp;
   float* P = p.P + ((size_t)b * p.R + r0) * p.Rp;
+  unsigned short* P16 = (unsigned short*)p.P + ((size_t)b * p.R + r0) * p.Rp;
   const int o2 = p.wc, o3 = p.wc + 1;
+  auto score = [&](int s, float v) { return (E0[s] + E1[s + 1] + E2[s + o2] + E3[s + o3]) * v * p.scale; };
   float m = -INFINITY;
   for (int s = lane; s < p.R; s += 64) {
     const float v = vr[s];
     if (v >= 0.f) {      // a key: sy < hc-1 and sx < wc-1, so s + wc + 1 < R
-      const float sc = (E0[s] + E1[s + 1] + E2[s + o2] + E3[s + o3]) * v * p.scale;
-      P[s] = sc;
+      const float sc = score(s, v);
+      if (!BF16) P[s] = sc;
       m = fmaxf(m, sc);
     }
   }
@@ -525,9 +531,10 @@ __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   float sum = 0.f;
   for (int s = lane; s < p.R; s += 64) {
-    if (vr[s] >= 0.f) {
-      const float e = expf(P[s] - m);      // each lane re-reads only what it wrote itself
-      P[s] = e;
+    const float v = vr[s];
+    if (v >= 0.f) {
+      const float e = expf((BF16 ? score(s, v) : P[s]) - m);      // fp32: each lane re-reads only what it wrote itself
+      if (!BF16) P[s] = e;
       sum += e;
     }
   }
@@ -536,13 +543,17 @@ __global__ __launch_bounds__(256) void att2_softmax_kernel(const AttParams p) {
   const float inv = 1.f / sum;
   for (int s = lane; s < p.Rp; s += 64) {
     float o = 0.f;
-    if (s < p.R && vr[s] >= 0.f) o = P[s] * inv;
-    P[s] = o;
+    const float v = s < p.R ? vr[s] : -1.f;
+    if (v >= 0.f) o = (BF16 ? expf(score(s, v) - m) : P[s]) * inv;
+    if (BF16) P16[s] = (unsigned short)(pack_bf16x2(o, 0.f) & 0xffffu);
+    else P[s] = o;
   }
 }
 
-// The same with the whole row in registers (R <= 64 * NV): E is read once, P written once.
-template <int NV>
+// The same with the whole row in registers (R <= 64 * NV): E is read once, P written once.  (A lane owning pairs of
+// adjacent columns -- 8-byte loads, half as many instructions -- was measured: 1.6x slower, the shifted operands are
+// 4-byte aligned and every such load splits.)
+template <int NV, bool BF16>
 __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
   int b, iy, ix;
@@ -553,7 +564,7 @@ __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p
   const float* E2 = E0 + (size_t)p.wc * p.Rp;
   const float* E3 = E2 + p.Rp;
   const float* vr = p.validR + (size_t)b * p.Rp;
-  float* P = p.P + ((size_t)b * p.R + r0) * p.Rp;
+  char* P = (char*)p.P + ((size_t)b * p.R + r0) * p.Rp * (BF16 ? 2 : 4);
   const int o2 = p.wc, o3 = p.wc + 1;
   float v[NV];
   float m = -INFINITY;
@@ -595,36 +606,50 @@ __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
   const float inv = 1.f / sum;
+  if (BF16) {
+    // columns lane + 64k: neighbours in a row are neighbour lanes.  One exchange per two k: the even lanes pack and store
+    // the pairs of row k, the odd lanes those of row k + 1 (4-byte stores; Rp is a multiple of 64 in bf16 mode)
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int s = lane + 64 * k;
-    if (s < p.Rp) P[s] = v[k] * inv;
+    for (int k = 0; k < NV; k += 2) {
+      const float a = v[k] * inv, c = v[k + 1] * inv;
+      const float got = __shfl_xor((lane & 1) ? a : c, 1);
+      const int s = (lane & 1) ? lane - 1 + 64 * (k + 1) : lane + 64 * k;
+      if (s < p.Rp) *(unsigned*)(P + s * 2) = (lane & 1) ? pack_bf16x2(got, c) : pack_bf16x2(a, got);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int s = lane + 64 * k;
+      if (s < p.Rp) *(float*)(P + s * 4) = v[k] * inv;
+    }
   }
 }
 
 // One wave per class-grid row r: P~[r][s] = sum over the <= 4 patches (query r-d, key s-d) that pair pixel r with pixel s.
-// P is zero at non-key columns, so only s - d < 0 needs a test on the key side.  Overwrites E.
+// P is zero at non-key columns, so only s - d < 0 needs a test on the key side.  Overwrites E.  P and P~ are fp32, or
+// bf16 in bf16 mode (P~: the sum of the four rounded P values, rounded once, packed into the front half of E).
+// This form (any wc): two adjacent columns per lane, element loads.
 template <bool BF16>
 __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
   const int lane = threadIdx.x & 63;
   int b, ry, rx;
   if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hc, p.wc, b, ry, rx)) return;
   const int r = ry * p.wc + rx;
-  const float* Pb = p.P + (size_t)b * p.R * p.Rp;
-  // row r of P~: fp32, or bf16 packed into the front half of the E buffer (rounded once, here)
-  char* out = (char*)p.E + ((size_t)b * p.R + r) * p.Rp * (BF16 ? 2 : 4);
-  const float* src[4];
+  constexpr int ES = BF16 ? 2 : 4;
+  const char* Pb = (const char*)p.P + (size_t)b * p.R * p.Rp * ES;
+  char* out = (char*)p.E + ((size_t)b * p.R + r) * p.Rp * ES;
+  const char* src[4];
   int off[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const int dy = d >> 1, dx = d & 1, qy = ry - dy, qx = rx - dx;
     const bool ok = qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;       // wave-uniform
-    src[d] = ok ? Pb + (size_t)(qy * p.wc + qx) * p.Rp : nullptr;
+    src[d] = ok ? Pb + (size_t)(qy * p.wc + qx) * p.Rp * ES : nullptr;
     off[d] = dy * p.wc + dx;
   }
-  // two adjacent columns per lane, 4 column pairs per batch: 32 unconditional loads in front of a scheduling barrier
-  // (see att2_softmax_reg_kernel); a row that does not exist (src null, wave-uniform) reads row 0 of P and is masked
-  const float* rowp[4];
+  // 4 column pairs per batch: 32 unconditional loads in front of a scheduling barrier (see att2_softmax_reg_kernel); a
+  // row that does not exist (src null, wave-uniform) reads row 0 of P and is masked
+  const char* rowp[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) rowp[d] = src[d] ? src[d] : Pb;
   for (int s00 = 2 * lane; s00 < p.Rp; s00 += 512) {        // Rp is even
@@ -634,7 +659,11 @@ __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) v[g][u][d] = rowp[d][min(max(s00 + g * 128 + u - off[d], 0), p.Rp - 1)];
+        for (int d = 0; d < 4; ++d) {
+          const int col = min(max(s00 + g * 128 + u - off[d], 0), p.Rp - 1);
+          if (BF16) v[g][u][d] = bf16_lo(((const unsigned short*)rowp[d])[col]);
+          else v[g][u][d] = ((const float*)rowp[d])[col];
+        }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -647,6 +676,68 @@ __global__ __launch_bounds__(256) void att2_boxsum_kernel(const AttParams p) {
         for (int d = 0; d < 4; ++d) a[u] += (src[d] && s0 + u >= off[d] && s0 + u < p.R) ? v[g][u][d] : 0.f;
       if (BF16) *(unsigned*)(out + s0 * 2) = pack_bf16x2(a[0], a[1]);
       else *(float2*)(out + s0 * 4) = make_float2(a[0], a[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same for wc % 4 == 0 (every standard size): four adjacent columns per lane.  The aligned start of the group in
+// source row d is s0 - dy * wc (a multiple of 4: one 16-byte / 8-byte load); the dx = 1 rows need the element in front
+// of it as well (one more element load): 6 loads per 4 columns instead of 16.
+template <bool BF16>
+__global__ __launch_bounds__(256) void att2_boxsum4_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  int b, ry, rx;
+  if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hc, p.wc, b, ry, rx)) return;
+  const int r = ry * p.wc + rx;
+  constexpr int ES = BF16 ? 2 : 4;
+  constexpr int G = 4;
+  const char* Pb = (const char*)p.P + (size_t)b * p.R * p.Rp * ES;
+  char* out = (char*)p.E + ((size_t)b * p.R + r) * p.Rp * ES;
+  bool ok[4];
+  const char* rowp[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int dy = d >> 1, dx = d & 1, qy = ry - dy, qx = rx - dx;
+    ok[d] = qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;               // wave-uniform
+    rowp[d] = ok[d] ? Pb + (size_t)(qy * p.wc + qx) * p.Rp * ES : Pb;   // a row that does not exist reads row 0, masked
+  }
+  for (int s00 = 4 * lane; s00 < p.Rp; s00 += 256 * G) {      // Rp is a multiple of 32
+    f32x4 q[G][4];
+    float e[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int s0 = min(s00 + g * 256, p.Rp - 4);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int a0 = max(s0 - (d >> 1) * p.wc, 0);
+        if (BF16) {
+          const uint2 t = *(const uint2*)(rowp[d] + a0 * 2);
+          q[g][d] = (f32x4){bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y)};
+          if (d & 1) e[g][d >> 1] = bf16_lo(((const unsigned short*)rowp[d])[max(a0 - 1, 0)]);
+        } else {
+          q[g][d] = *(const f32x4*)(rowp[d] + a0 * 4);
+          if (d & 1) e[g][d >> 1] = ((const float*)rowp[d])[max(a0 - 1, 0)];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int s0 = s00 + g * 256;
+      if (s0 >= p.Rp) break;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int off = (d >> 1) * p.wc + (d & 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float val = (d & 1) ? (u == 0 ? e[g][d >> 1] : q[g][d][u - 1]) : q[g][d][u];
+          a[u] += (ok[d] && s0 + u >= off && s0 + u < p.R) ? val : 0.f;
+        }
+      }
+      if (BF16) *(uint2*)(out + s0 * 2) = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+      else *(f32x4*)(out + s0 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -729,6 +820,7 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
 }
 
 // similar (B, L, hs, ws) <- P: channel = key j, pixel = query i (splitcam.py:106-108), for the unit-test entry point
+template <bool BF16>
 __global__ void att2_similar_kernel(const AttParams p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // over B*L*L, query fastest
   if (idx >= (long)p.B * p.L * p.L) return;
@@ -736,7 +828,8 @@ __global__ void att2_similar_kernel(const AttParams p) {
   const long bj = idx / p.L;
   const int j = bj % p.L, b = bj / p.L;
   const int r = (i / p.ws) * p.wc + i % p.ws, s = (j / p.ws) * p.wc + j % p.ws;
-  p.similar[idx] = p.P[((size_t)b * p.R + r) * p.Rp + s];
+  const size_t at = ((size_t)b * p.R + r) * p.Rp + s;
+  p.similar[idx] = BF16 ? bf16_lo(((const unsigned short*)p.P)[at]) : p.P[at];
 }
 
 template <bool BF16>
@@ -763,19 +856,20 @@ static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
     const long rows = tile_order_count(p.B, p.hs, p.ws);
     ProfScope ps_(st, PL_ATT_SOFTMAX);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (p.Rp <= 64 * 16) hipLaunchKernelGGL(att2_softmax_reg_kernel<16>, grid, dim3(256), 0, st, p);
-    else if (p.Rp <= 64 * 64) hipLaunchKernelGGL(att2_softmax_reg_kernel<64>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(att2_softmax_kernel, grid, dim3(256), 0, st, p);
+    if (p.Rp <= 64 * 16) hipLaunchKernelGGL((att2_softmax_reg_kernel<16, BF16>), grid, dim3(256), 0, st, p);
+    else if (p.Rp <= 64 * 64) hipLaunchKernelGGL((att2_softmax_reg_kernel<64, BF16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(att2_softmax_kernel<BF16>, grid, dim3(256), 0, st, p);
   }
   if (p.similar) {
     const long n = (long)p.B * p.L * p.L;
     ProfScope ps_(st, PL_LAYOUT);
-    hipLaunchKernelGGL(att2_similar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(att2_similar_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
   }
   {
     const long rows = tile_order_count(p.B, p.hc, p.wc);
     ProfScope ps_(st, PL_ATT_BOXSUM);
-    hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    if (p.wc % 4 == 0) hipLaunchKernelGGL(att2_boxsum4_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   }
   {
     constexpr int PT = 4;

@@ -229,7 +229,7 @@ struct AttParams {
   int hc, wc, R, Rp;
   float* xT;           // [B][4 classes][96][Rp]  workspace: x transposed per parity class (A operand of the P~.V GEMM)
   float* E;            // [B][R][Rp] workspace: pixel-pair dot products E, later overwritten by P~
-  float* P;            // [B][R][Rp] workspace: softmax probabilities in class-grid indexing (row = query, column = key)
+  float* P;            // [B][R][Rp] workspace (fp32, or bf16 in bf16 mode): softmax probabilities in class-grid indexing (row = query, column = key)
   float* validR;       // [B][Rp]    workspace: key validity in class-grid indexing: 1 / 0, -1 where the position is not a key
   float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
   int bf16;            // x, xn, xT, P~ (in the E buffer) and out hold bf16; Rp is then a multiple of 64

@@ -119,17 +119,24 @@ def test_op_two_source_conv_bf16(eng, kind):
     _layer_close(y, O.gated_conv(torch.from_numpy(cat), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu", BF))
 
 
-def test_op_attention_bf16(eng):
-    """bf16 keys / probabilities / values, fp32 scores and softmax; soft (non-saturated) scores."""
+@pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 24, 40), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
+def test_op_attention_bf16(eng, shape):
+    """bf16 keys / probabilities / values, fp32 scores and softmax; soft (non-saturated) scores.  16x12: class grid 8x6
+    (element-load box sum); 16x16 / 24x40: wc % 4 == 0 (vector box sum); 132x136: 4488 class-grid pixels, the softmax
+    form for rows that do not fit in registers."""
     from oracle import sketchedit_oracle as O
-    x = 0.004 * synth.uniform(5, "att96s.x", (2, 96, 16, 12), -1, 1)
-    full = (synth.uniform(5, "att96s.m", (2, 1, 64, 48), 0, 1) < 0.5).astype(np.float32)
-    full[0, :, :, 24:] = 1.0
+    B, h, w = shape
+    x = 0.004 * synth.uniform(5, "att96s.x%d" % h, (B, 96, h, w), -1, 1)
+    full = (synth.uniform(5, "att96s.m%d" % h, (B, 1, 4 * h, 4 * w), 0, 1) < 0.5).astype(np.float32)
+    full[0, :, :, 2 * w:] = 1.0
     out, sim = eng.attention(_cuda(x), _cuda(full), want_similar=True, bf16=True)
     xr = torch.from_numpy(x).to(BF).float()
     ro, rp = O.contextual_attention(xr, torch.from_numpy(full), BF)
-    assert float(np.abs(_np(sim) - _np(rp)).max()) < 1e-5             # fp32 softmax of fp32-accumulated bf16 products
-    # out: sums of <= 4L products of bf16 P (the kernel rounds the box-summed P~, the oracle P) and bf16 values
+    # P: fp32 softmax of fp32-accumulated bf16 products, stored rounded to bf16 (the oracle rounds it before the
+    # reconstruction, attention_reconstruct): one bf16 step where the fp32 values differ in the last bits
+    rp = _np(rp)
+    assert bool((np.abs(_np(sim) - rp) <= 2.0 ** -8 * np.abs(rp) + 1e-6).all())
+    # out: sums of <= 4L products of bf16 P (box-summed and rounded once more on the GPU) and bf16 values
     assert float(np.abs(_np(out) - _np(ro)).max()) < 2.0 ** -7 * float(ro.abs().max())
 
 

@@ -202,18 +202,23 @@ def test_op_low_latency_shapes_vs_oracle(eng, shape):
     assert _md(y, ref) < TOL_OP
 
 
-def test_op_attention_soft_scores_vs_oracle(eng):
+@pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
+def test_op_attention_soft_scores_vs_oracle(eng, shape):
     """Small activations keep the softmax far from one-hot (10 * <q, k> of order 1), so a wrong pairing of pixels in
-    the space-to-depth form (se_attention.hip) or a mis-scaled score cannot hide behind a saturated softmax."""
+    the space-to-depth form (se_attention.hip) or a mis-scaled score cannot hide behind a saturated softmax.
+    16x12: class grid 8x6 (element-load box sum); 16x16: wc % 4 == 0 (vector box sum); 132x136: 4488 class-grid pixels,
+    the softmax form for rows that do not fit in registers."""
     from oracle import sketchedit_oracle as O
-    x = 0.004 * synth.uniform(5, "att96s.x", (2, 96, 16, 12), -1, 1)
-    full = (synth.uniform(5, "att96s.m", (2, 1, 64, 48), 0, 1) < 0.5).astype(np.float32)
-    full[0, :, :, 24:] = 1.0
+    B, h, w = shape
+    x = 0.004 * synth.uniform(5, "att96s.x%d" % h, (B, 96, h, w), -1, 1)
+    full = (synth.uniform(5, "att96s.m%d" % h, (B, 1, 4 * h, 4 * w), 0, 1) < 0.5).astype(np.float32)
+    full[0, :, :, 2 * w:] = 1.0
     out, sim = eng.attention(_cuda(x), _cuda(full), want_similar=True)
     ro, rp = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
-    assert float(rp.max()) < 0.5 and float(rp.min()) > 1e-3          # far from one-hot
+    if h < 100:
+        assert float(rp.max()) < 0.5 and float(rp.min()) > 1e-3          # far from one-hot
     assert _md(sim, rp) < 2e-6
-    assert _md(out, ro) < 1e-5 * float(ro.abs().max())
+    assert _md(out, ro) < (1e-5 if h < 100 else 1e-4) * float(ro.abs().max())      # up to 4L products per output
 
 
 def test_op_attention_vs_oracle(eng):

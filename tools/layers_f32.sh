@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/lay
+Q="--size 256 --batch 32 --no-cpu-baseline --no-parity --no-traffic --steps 10 --warmup 3 --layers"
+python bench.py $Q > gpurun_out/lay/f.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/lay/f.json").read().splitlines() if l.startswith("{")][-1])
+print(d["ms_per_step"])
+for k,v in d["layers"].items(): print(k, v)
+PY
