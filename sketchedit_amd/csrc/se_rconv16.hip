@@ -6,7 +6,8 @@
 //   * the input tile of a 16 x 16 block of outputs (18 x 18 pixels with the halo, all 96 channels, 61 KB) is DMA'd into
 //     LDS ONCE in its natural pixel-major layout, and the MFMA B fragments of all 9 taps are read straight from it -- a
 //     tap is an address offset, nothing is re-staged;
-//   * one workgroup = 8 waves = 256 output pixels, so a weight tile serves twice as many pixels.
+//   * one workgroup = 8 waves = 256 output pixels, so a weight tile serves twice as many pixels; a wave owns 96 packed
+//     rows (3 feature tiles + their gate tiles) x 64 pixels (4 tile rows): 20 fragment reads per 48 MFMAs.
 // 407 KB staged per 256 outputs instead of 1120 KB.  Weights: the very image pack_layer16 builds for the gather-GEMM
 // ([14 chunks][192 rows][64 k], k = tap * 96 + channel): a 32-k MFMA step never straddles a tap because 96 = 3 * 32.
 //
@@ -82,51 +83,61 @@ __global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
   int off0, off1;
   frag_offsets(lane, off0, off1);
 
-  f32x4 acc[12][2];
+  // Wave tiling: 96 packed rows x 64 pixels.  Wave w = (nh, pg): feature tiles 3 nh .. 3 nh + 2 with their gate tiles
+  // (+6), pixel rows 4 pg .. 4 pg + 3 of the tile.  (The first version gave every wave all 192 rows x 32 pixels: 28
+  // fragment reads per 48 MFMAs, 149 B/clk/CU of LDS reads against the 128 B/clk the LDS delivers; the squarer tile needs 20.)
+  const int nh = w & 1, pg = w >> 1;
+  constexpr int NTW = 6, PT = 4;
+  f32x4 acc[NTW][PT];
 #pragma unroll
-  for (int nt = 0; nt < 12; ++nt)
+  for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wrow0 = nh * 3 * 2048;                                          // byte offset of this wave's first row tile
 
   dma_wait_all();
   __syncthreads();
-  // A bf16 MFMA is ~17 cycles per SIMD and an A (weight) fragment feeds only two of them, so fragments are kept DEPTH
-  // deep in flight (a one-fragment look-ahead exposed the LDS latency on every fragment: ~42 cycles per MFMA).  The B
-  // (pixel) fragments come from the raw tile, which never changes: those of the next chunk are read during this one.
-  constexpr int DEPTH = 6;
+  // A bf16 MFMA is ~17 cycles per SIMD and an A (weight) fragment feeds four of them, so fragments are kept DEPTH deep
+  // in flight (a one-fragment look-ahead exposed the LDS latency on every fragment).  The B (pixel) fragments come from
+  // the raw tile, which never changes: those of the next chunk are read during this one.
+  constexpr int DEPTH = 4;
   auto bfrag = [&](int s, int pt) -> bf16x8 {          // s = 32-k step (compile-time): tap s / 3, channels 32 (s % 3) ..
     const int tap = s / 3, kk = s - tap * 3, ky = tap / 3, kx = tap - ky * 3;
-    return *(const bf16x8*)(Raw + (2 * w + pt + ky) * ROWB + bk[kx] + kk * 64);
+    return *(const bf16x8*)(Raw + (4 * pg + pt + ky) * ROWB + bk[kx] + kk * 64);
   };
-  bf16x8 xb[2][2], xn[2][2];
+  auto afrag = [&](const char* Wt, int u) -> bf16x8 {  // u = 0..11: k-half u / 6, wave row tile u % 6
+    const int i = u % NTW;
+    return *(const bf16x8*)(Wt + wrow0 + (i < 3 ? i : i + 3) * 2048 + (u / NTW ? off1 : off0));
+  };
+  bf16x8 xb[2][PT], xn[2][PT];
 #pragma unroll
   for (int half = 0; half < 2; ++half)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) xb[half][pt] = bfrag(half, pt);
+    for (int pt = 0; pt < PT; ++pt) xb[half][pt] = bfrag(half, pt);
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {      // fully unrolled: taps, k-steps, buffers and register rotation are compile-time
     const int buf = ch & 1;
     const char* Wt = Wb + buf * WB;
-    const int nu = (ch * 2 + 1 < NSTEP) ? 24 : 12;     // the second half of the last chunk is K padding
+    const int nu = (ch * 2 + 1 < NSTEP) ? 2 * NTW : NTW;     // the second half of the last chunk is K padding
     bf16x8 wq[DEPTH];
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) wq[u] = *(const bf16x8*)(Wt + (u % 12) * 2048 + (u / 12 ? off1 : off0));
+    for (int u = 0; u < DEPTH; ++u) wq[u] = afrag(Wt, u);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 24; ++u) {
+    for (int u = 0; u < 2 * NTW; ++u) {
       if (u >= nu) continue;
-      const int half = u / 12, nt = u % 12;
+      const int half = u / NTW, nt = u % NTW;
       const bf16x8 wa = wq[u % DEPTH];
-      if (u + DEPTH < nu) wq[u % DEPTH] = *(const bf16x8*)(Wt + ((u + DEPTH) % 12) * 2048 + ((u + DEPTH) / 12 ? off1 : off0));
-      // the next chunk's pixel fragments (the raw tile never changes)
-      if (u >= 4 && u < 8 && ch + 1 < NCH) {
-        const int h2 = (u - 4) >> 1, pt2 = (u - 4) & 1, s2 = (ch + 1) * 2 + h2;
+      if (u + DEPTH < nu) wq[u % DEPTH] = afrag(Wt, u + DEPTH);
+      // the next chunk's pixel fragments (the raw tile never changes): one per MFMA group from the third on
+      if (u >= 2 && u < 2 + 2 * PT && ch + 1 < NCH) {
+        const int h2 = (u - 2) / PT, pt2 = (u - 2) % PT, s2 = (ch + 1) * 2 + h2;
         if (s2 < NSTEP) xn[h2][pt2] = bfrag(s2, pt2);
       }
       // pin the order (hipcc would sink every read to just in front of its MFMAs and wait lgkmcnt(0) there)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < PT; ++pt)
         acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[half][pt], acc[nt][pt], 0, 0, 0);
       // the next chunk's weight DMA, one piece per MFMA group (a burst stalls the wave)
       if (u < 3 && ch + 1 < NCH) dma_w(ch + 1, buf ^ 1, u);
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) xb[half][pt] = xn[half][pt];
+      for (int pt = 0; pt < PT; ++pt) xb[half][pt] = xn[half][pt];
     dma_wait_all();
     __syncthreads();
   }
@@ -148,18 +159,18 @@ __global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
   constexpr int OPX = 208;
   const int q = lane >> 4, jx = lane & 15;
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    char* o = Raw + ((2 * w + pt) * 16 + jx) * OPX;
+  for (int pt = 0; pt < PT; ++pt) {
+    char* o = Raw + ((4 * pg + pt) * 16 + jx) * OPX;
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
-      const int c0 = nt * 16 + q * 4;
+    for (int nt = 0; nt < 3; ++nt) {
+      const int c0 = (nh * 3 + nt) * 16 + q * 4;
       const f32x4 bf = *(const f32x4*)(p.bias + c0);
       const f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
       float ov[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float f = acc[nt][pt][r] + bf[r];
-        const float g = acc[nt + 6][pt][r] + bg[r];
+        const float g = acc[nt + 3][pt][r] + bg[r];
         ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
       }
       *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
