@@ -75,6 +75,7 @@ struct Layer {
   // bf16 image (BASELINE config 5): same row order and slot swizzle, 64 bf16 k-values per 128-byte row, 8-channel granules
   float* d_w16 = nullptr;
   int nch16 = 0, CGp16 = 0;
+  float* d_w16s = nullptr;    // 96 -> 192 3x3 only: the 32-k step image of the 8 x 16 raw-tile kernel (se_rconv16.hip)
 };
 
 // ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
@@ -333,6 +334,30 @@ int pack_layer16(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   return 0;
 }
 
+// bf16 image for rconv16b_kernel (96 -> 192, 3x3): [27 steps = tap * 3 + 32-channel group][12 row tiles][16 rows][32 k],
+// rows in the N=192 order (features, then gates); granule g (8 k) of row r at slot g ^ F[r >> 2], F = {0, 2, 3, 1}.
+int pack_rconv16(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const int F[4] = {0, 2, 3, 1};
+  std::vector<unsigned short> img((size_t)27 * 192 * 32, 0);
+  for (int n = 0; n < 192; ++n) {
+    const int oc = out_channel_of_row(GC_N192, n, 96, 192);
+    const int rt = n / 16, r = n % 16;
+    for (int s = 0; s < 27; ++s) {
+      const int tap = s / 3, kk = s % 3, ty = tap / 3, tx = tap % 3;
+      for (int e = 0; e < 32; ++e) {
+        const int ic = kk * 32 + e, g = e / 8;
+        const float v = L.w[(((size_t)oc * d.cin + ic) * 3 + ty) * 3 + tx];
+        img[((size_t)s * 12 + rt) * 512 + r * 32 + ((g ^ F[r >> 2]) * 8) + (e % 8)] = bf16_bits(v);
+      }
+    }
+  }
+  if (L.d_w16s) (void)hipFree(L.d_w16s);
+  HIPCHK(c, hipMalloc(&L.d_w16s, img.size() * 2));
+  HIPCHK(c, hipMemcpy(L.d_w16s, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  return 0;
+}
+
 // Winograd F(2x2,3x3) weights: U[pos] = (G g G^T)[xi][nu] per (out, in) pair, packed per position like a 1x1
 // conv Cin -> 192 (Cin = 96, or 192 for the two-source layers) in the N=192 row order (features then gates)
 // with the same slot swizzle.
@@ -506,6 +531,7 @@ int pack_net_layer(se_ctx* c, Layer& L) {
     }
     const int rc = pack_layer16(c, L, identity_map8(d.cin));
     if (rc) return rc;
+    if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && pack_rconv16(c, L)) return 1;
   }
   std::vector<int> m;
   if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
@@ -579,12 +605,13 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
       (long long)B * Hin * Win * 192 < (1ll << 31)) {
     RConvParams rp;
     memset(&rp, 0, sizeof rp);
-    rp.src = src0; rp.wpk = L.d_w16; rp.bias = L.d_b; rp.dst = dst;
+    const bool small = rconv16_small_tiles() && L.d_w16s;     // 8 x 16 tiles, 32-k step image, no K padding
+    rp.src = src0; rp.wpk = small ? L.d_w16s : L.d_w16; rp.bias = L.d_b; rp.dst = dst;
     rp.B = B; rp.h = Hin; rp.w = Win; rp.d = d.rate; rp.hs = Hin / d.rate; rp.ws = Win / d.rate;
-    rp.ty = (rp.hs + 15) / 16; rp.tx = (rp.ws + 15) / 16;
+    rp.ty = small ? (rp.hs + 7) / 8 : (rp.hs + 15) / 16; rp.tx = (rp.ws + 15) / 16;
     rp.act = d.act; rp.xcd = xcd_remap_enabled();
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
-    set_launch_cost(alg, 2.0 * 2.0 * (double)B * Hin * Win * 96, d.name, 2.0 * (double)B * Hin * Win * 192.0 * 896.0);
+    set_launch_cost(alg, 2.0 * 2.0 * (double)B * Hin * Win * 96, d.name, 2.0 * (double)B * Hin * Win * 192.0 * (small ? 864.0 : 896.0));
     HIPCHK(c, launch_rconv16(rp, c->st));
     return 0;
   }
@@ -1146,6 +1173,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_u) (void)hipFree(kv.second.d_u);
       if (kv.second.d_ub) (void)hipFree(kv.second.d_ub);
       if (kv.second.d_w16) (void)hipFree(kv.second.d_w16);
+      if (kv.second.d_w16s) (void)hipFree(kv.second.d_w16s);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
@@ -1476,6 +1504,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
     if (Cout % 8) rc = fail(c, "gated conv needs Cout %% 8 == 0");
     if (!rc) rc = pack_layer(c, L, identity_map(CinT));
     if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
+    if (!rc && bf && k == 3 && stride == 1 && !upsample && CinT == 96 && Cout == 192 && !Cin1) rc = pack_rconv16(c, L);
     if (!rc) {
       int Ho, Wo;
       c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
@@ -1494,6 +1523,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_u) (void)hipFree(L.d_u);
   if (L.d_ub) (void)hipFree(L.d_ub);
   if (L.d_w16) (void)hipFree(L.d_w16);
+  if (L.d_w16s) (void)hipFree(L.d_w16s);
   return rc;
 }
 

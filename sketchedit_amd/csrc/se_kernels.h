@@ -119,16 +119,18 @@ hipError_t launch_winoup(const WinoParams& p, hipStream_t st);
 // ---------------------------------------------------------------------------------------------
 struct RConvParams {
   const void* src;     // bf16 NHWC [B][h][w][96]
-  const void* wpk;     // bf16 image of pack_layer16: [14 chunks][192 rows][64 k]
+  const void* wpk;     // bf16 weights: image of pack_layer16 [14 chunks][192 rows][64 k] (16 x 16 tiles) or of
+                       // pack_rconv16 [27 steps][12 row tiles][16 rows][32 k] (8 x 16 tiles)
   const float* bias;   // [192] packed-row order (features, then gates)
   void* dst;           // bf16 NHWC [B][h][w][96]
   int B, h, w, d;      // dilation d; h % d == 0 and w % d == 0
   int hs, ws;          // polyphase sub-image size h/d x w/d
-  int ty, tx;          // 16 x 16 tiles per sub-image
+  int ty, tx;          // tiles per sub-image (16 x 16, or 8 rows x 16 columns)
   int act;             // 0 ELU, 1 ReLU
   int xcd;             // 1: XCD-aware tile order
 };
 hipError_t launch_rconv16(const RConvParams& p, hipStream_t st);
+bool rconv16_small_tiles();   // 8 x 16 tiles, two workgroups per CU (default) / SE_RCONV16_TILE=16
 
 // ---------------------------------------------------------------------------------------------
 // Raw-tile form of the narrow (MIXED-row) stride-1 gated convs, fp32 and bf16 (se_rtile.hip)

@@ -188,7 +188,172 @@ __global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same layer on 8 x 16 tiles with TWO workgroups per CU (the default; SE_RCONV16_TILE=16 selects the kernel above).
+//
+// With its 109 KB of LDS the 16 x 16 kernel owns a CU alone: its prologue (memory latency + 85 KB of fill), its epilogue
+// (exp / rcp, LDS transpose, stores) and every barrier wait are MFMA-idle time -- 41 % pipe utilisation.  Here a
+// workgroup is 4 waves on an 8 x 16 tile (raw tile 10 x 18 pixels = 34 KB) and the weights come in 32-k STEPS from their
+// own image ([27 steps][12 row tiles][16 rows][32 k], pack_rconv16 in se_api.hip: no K padding, 12 KB per step, a ring of
+// three steps = 36 KB): 70 KB per workgroup, two per CU, and whatever one of them waits for the other fills with MFMAs.
+// The weight stream per pixel doubles (324 KB per 128 pixels); the LDS-DMA path delivers > 50 B/clk/CU with two
+// workgroups resident (tools/ubench/lds_fill_rate.hip), 2.9 MB per CU and layer is ~25 us of it, hidden.
+// A-fragment tile in LDS: 16 rows x 64 bytes, granule g of row r at slot g ^ F[r >> 2], F = {0, 2, 3, 1}: the four
+// non-contiguous 16-lane groups of a ds_read_b128 each hit 16 distinct 16-byte slots of the 256-byte bank row.
+__global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
+  constexpr int TY = 8, TX = 16, RSY = TY + 2, RSX = TX + 2;
+  constexpr int ROWB = RSX * 192;                     // bytes per raw tile row
+  constexpr int NDMA = (RSY * RSX * 12 + 63) / 64;    // 34 LDS-DMA instructions fill the raw tile
+  constexpr int RAWB = NDMA * 1024;
+  constexpr int WSB = 12 * 1024;                      // one 32-k weight step: 12 row tiles of 1 KB
+  constexpr int NSTEP = 27, NS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Raw = smem;
+  char* Wb = smem + RAWB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lb = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tpi = p.ty * p.tx, per_img = p.d * p.d * tpi;
+  const int b = lb / per_img, r1 = lb - b * per_img;
+  const int ph = r1 / tpi, t = r1 - ph * tpi;
+  const int py = ph / p.d, px = ph - py * p.d;
+  const int ty0 = (t / p.tx) * TY, tx0 = (t % p.tx) * TX;
+
+  const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.h * p.w * 192u);
+  const unsigned lds_raw = lds_addr_of(Raw), lds_w = lds_addr_of(Wb);
+  auto dma_w = [&](int s, int j) {                    // row tile j * 4 + w of weight step s into ring slot s % NS
+    const int rt = j * 4 + w;
+    glds16_s((const char*)p.wpk + (size_t)s * WSB + rt * 1024, (unsigned)lane * 16u, lds_w + (s % NS) * WSB + rt * 1024);
+  };
+  // ---- prologue: weight step 0, the raw tile, weight step 1 (in this order: the loop's counted waits rely on it)
+  dma_w(0, 0); dma_w(0, 1); dma_w(0, 2);
+#pragma unroll
+  for (int i0 = 0; i0 < (NDMA + 3) / 4; ++i0) {
+    const int i = i0 * 4 + w;
+    if (i < NDMA) {
+      const int q = i * 64 + lane;                   // granule slot of the raw tile
+      const int pix = q / 12, gs = q - pix * 12;
+      const int row = pix / RSX, c = pix - row * RSX;
+      const int gl = gs ^ (((c >> 2) & 1) << 1);     // stored slot gs holds logical granule gl (layout note at the top)
+      const int sy = ty0 - 1 + row, sx = tx0 - 1 + c;
+      const bool ok = q < RSY * RSX * 12 && (unsigned)sy < (unsigned)p.hs && (unsigned)sx < (unsigned)p.ws;
+      const unsigned off = (unsigned)((b * p.h + sy * p.d + py) * p.w + sx * p.d + px) * 192u + (unsigned)gl * 16u;
+      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);
+    }
+  }
+  dma_w(1, 0); dma_w(1, 1); dma_w(1, 2);
+
+  int bk[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int c = (lane & 15) + kx;
+    bk[kx] = c * 192 + (((lane >> 4) ^ (((c >> 2) & 1) << 1)) << 4);
+  }
+  const int nh = w & 1, pg = w >> 1;                  // wave = 96 packed rows (3 feature tiles + their gate tiles) x 64 pixels
+  constexpr int NTW = 6, PT = 4;
+  // A fragment of this lane inside a 1 KB row tile (swizzle F = {0,2,3,1} by row >> 2)
+  const int rq = (lane & 15) >> 2;
+  const int aoff = (lane & 15) * 64 + (((lane >> 4) ^ ((0x78 >> (rq * 2)) & 3)) << 4) + nh * 3 * 1024;
+
+  f32x4 acc[NTW][PT];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto bfrag = [&](int s, int pt) -> bf16x8 {          // s = 32-k step (compile-time): tap s / 3, channels 32 (s % 3) ..
+    const int tap = s / 3, kk = s - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+    return *(const bf16x8*)(Raw + (4 * pg + pt + ky) * ROWB + bk[kx] + kk * 64);
+  };
+  auto afrag = [&](int s, int i) -> bf16x8 {           // wave row tile i = 0..5 of step s
+    return *(const bf16x8*)(Wb + (s % NS) * WSB + aoff + (i < 3 ? i : i + 3) * 1024);
+  };
+  // weight step 0 and the raw tile have landed when at most the 3 DMAs of step 1 are outstanding (loads retire in order)
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  __syncthreads();
+  bf16x8 xb[PT], xn[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) xb[pt] = bfrag(0, pt);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {       // fully unrolled: taps, ring slots and register rotation are compile-time
+    constexpr int DEPTH = 3;
+    bf16x8 wq[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) wq[u] = afrag(s, u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+      const bf16x8 wa = wq[u % DEPTH];
+      if (u + DEPTH < NTW) wq[u % DEPTH] = afrag(s, u + DEPTH);
+      // the next step's pixel fragments (the raw tile never changes), one per MFMA group
+      if (u >= 1 && u < 1 + PT && s + 1 < NSTEP) xn[u - 1] = bfrag(s + 1, u - 1);
+      // pin the order (hipcc would sink every read to just in front of its MFMAs and wait lgkmcnt(0) there)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        acc[u][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[pt], acc[u][pt], 0, 0, 0);
+      // weight step s + 2 goes to the slot step s - 1 has left (everyone passed the barrier that ended it)
+      if (u < 3 && s + 2 < NSTEP) dma_w(s + 2, u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xb[pt] = xn[pt];
+    // step s + 1 was issued one step ago: at most the 3 DMAs of step s + 2 may still be in flight
+    if (s + 2 < NSTEP) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, gate, transposed through LDS (the raw tile's room), 16-byte stores (see the kernel above)
+  constexpr int OPX = 208;
+  const int q = lane >> 4, jx = lane & 15;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    char* o = Raw + ((4 * pg + pt) * 16 + jx) * OPX;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const int c0 = (nh * 3 + nt) * 16 + q * 4;
+      const f32x4 bf = *(const f32x4*)(p.bias + c0);
+      const f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
+      float ov[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float f = acc[nt][pt][r] + bf[r];
+        const float g = acc[nt + 3][pt][r] + bg[r];
+        ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
+      }
+      *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {                  // 128 pixels x 12 pieces of 16 bytes = 6 per thread
+    const int piece = it * 256 + tid;
+    const int pix = piece / 12, part = piece - pix * 12;
+    const int sy = ty0 + (pix >> 4), sx = tx0 + (pix & 15);
+    if (sy < p.hs && sx < p.ws)
+      *(uint4*)((char*)p.dst + ((size_t)(b * p.h + sy * p.d + py) * p.w + sx * p.d + px) * 192 + part * 16) =
+          *(const uint4*)(Raw + pix * OPX + part * 16);
+  }
+}
+
+bool rconv16_small_tiles() {
+  static const bool big = getenv("SE_RCONV16_TILE") && atoi(getenv("SE_RCONV16_TILE")) == 16;
+  return !big;
+}
+
 hipError_t launch_rconv16(const RConvParams& p, hipStream_t st) {
+  if (rconv16_small_tiles()) {
+    constexpr int LDS = 34 * 1024 + 3 * 12 * 1024;   // raw tile 34 KB + ring of three 12 KB weight steps
+    hipError_t e = ensure_max_lds((const void*)rconv16b_kernel, LDS);
+    if (e != hipSuccess) return e;
+    const int grid = p.B * p.d * p.d * p.ty * p.tx;
+    set_launch_grid(grid);
+    ProfScope ps_(st, PL_GCONV_N192);
+    hipLaunchKernelGGL(rconv16b_kernel, dim3(grid), dim3(256), LDS, st, p);
+    return hipGetLastError();
+  }
   constexpr int LDS = 61 * 1024 + 2 * 192 * 128;     // raw tile 61 KB + weight double buffer 48 KB
   {
     hipError_t e = ensure_max_lds((const void*)rconv16_kernel, LDS);
