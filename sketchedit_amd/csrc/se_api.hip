@@ -561,7 +561,8 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   const int KW = d.up ? 2 : d.k, KH = KW;
   RTileParams p;
   memset(&p, 0, sizeof p);
-  p.RH = 8 + KH - 1; p.RW = 16 + KW - 1;
+  const int TR = rtile_rows(bf);
+  p.RH = TR + KH - 1; p.RW = 16 + KW - 1;
   p.raw_bytes = (p.RH * p.RW * C0 * es + 1023) & ~1023;
   if (p.raw_bytes + nch * L.NP * 128 > 80 * 1024) return 0;                 // two workgroups per CU or not at all
   if ((long long)B * Hin * Win * C0 * es >= (1ll << 31)) return 0;
@@ -577,7 +578,7 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   p.nch = nch; p.NP = L.NP;
   udiv_magic_host((unsigned)(C0 * es / 16), &p.div_cg_m, &p.div_cg_l);
   udiv_magic_host((unsigned)p.RW, &p.div_rw_m, &p.div_rw_l);
-  p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
+  p.ty = (Hin + TR - 1) / TR; p.tx = (Win + 15) / 16;
   p.act = d.act; p.bf16 = bf ? 1 : 0; p.xcd = xcd_remap_enabled();
   {
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * d.k * d.k;

@@ -157,6 +157,7 @@ struct RTileParams {
   int act, bf16, xcd;
 };
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st);
+int rtile_rows(bool bf16);    // output rows per workgroup tile (8 fp32, 32 bf16)
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 conv 12 -> {1,3} raw output + fused tanh/sigmoid/composite (final layer of each decoder)

@@ -5,7 +5,8 @@
 // stages every input pixel once per tap (9x, 25x for the 5x5 layers) -- 16 KB of pixels + 6 KB of weights per 32-k chunk
 // and 128 outputs against 1536 cycles of fp32 MFMAs, i.e. 28.6 B/clk for two resident workgroups where the CU's LDS-DMA
 // sustains about 19 B/clk: the pipe sits at 65 % (profiles/r02_c2_pmc_summary.txt).  Here
-//   * the input tile of an 8 x 16 block of outputs (with its halo, every channel) is DMA'd into LDS ONCE, pixel-major,
+//   * the input tile of an 8 x 16 (fp32) / 32 x 16 (bf16) block of outputs (with its halo, every channel) is DMA'd into
+//     LDS ONCE, pixel-major,
 //     and the B fragments of every tap are read straight from it (a tap is an address offset);
 //   * the layer's WHOLE packed weight image (25 - 43 KB for these shapes) is resident in LDS, loaded in the prologue:
 //     the k loop has no staging, no vmcnt wait and no barrier at all.
@@ -23,10 +24,10 @@
 
 namespace se {
 
-template <int NT, bool BF16>
+template <int NT, int PT, bool BF16>
 __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   constexpr int ES = BF16 ? 2 : 4;           // bytes per stored element
-  constexpr int PT = 2;                      // a wave = 2 rows of 16 output pixels
+  constexpr int TR = 4 * PT;                 // a wave = PT rows of 16 output pixels, a workgroup = TR x 16 outputs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Raw = smem;
   char* Wres = smem + p.raw_bytes;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
     tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   }
   const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
-  const int ty0 = (t2 / p.tx) * 8, tx0 = (t2 % p.tx) * 16;
+  const int ty0 = (t2 / p.tx) * TR, tx0 = (t2 % p.tx) * 16;
   const int py = cls >> 1, px = cls & 1;
   const int pady = p.up2 ? 1 - py : p.pad, padx = p.up2 ? 1 - px : p.pad;
   const int pixb = p.C * ES;                 // bytes per source pixel
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   frag_offsets(lane, off0, off1);
   const int jx = lane & 15, g4 = lane >> 4;
   const int rowb = p.RW * pixb;                                          // bytes per raw tile row
-  const int xbase = ((2 * w) * p.RW + jx) * pixb;                        // this lane's pixel of the wave's first row
+  const int xbase = ((PT * w) * p.RW + jx) * pixb;                        // this lane's pixel of the wave's first row
 
   f32x4 acc[NT][PT];
 #pragma unroll
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
     const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int yy = ty0 + 2 * w + pt, xx = tx0 + jx;
+      const int yy = ty0 + PT * w + pt, xx = tx0 + jx;
       const f32x4 v = acc[nt][pt] + bq;
       const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
@@ -148,24 +149,29 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   }
 }
 
-template <int NT, bool BF16>
+template <int NT, int PT, bool BF16>
 static hipError_t launch_rtile_t(const RTileParams& p, hipStream_t st, int label) {
   const int lds = p.raw_bytes + p.nch * p.NP * 128;
   {
-    hipError_t e = ensure_max_lds((const void*)rtile_kernel<NT, BF16>, 80 * 1024);
+    hipError_t e = ensure_max_lds((const void*)rtile_kernel<NT, PT, BF16>, 80 * 1024);
     if (e != hipSuccess) return e;
   }
   const int tiles = p.B * p.ty * p.tx;
   const int grid = p.up2 ? class_tile_grid(tiles) : tiles;
   set_launch_grid(grid);
   ProfScope ps_(st, label);
-  hipLaunchKernelGGL((rtile_kernel<NT, BF16>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((rtile_kernel<NT, PT, BF16>), dim3(grid), dim3(256), lds, st, p);
   return hipGetLastError();
 }
 
+// Tile rows per workgroup.  fp32: 8 (a wave = 2 rows: 5 fragment reads per 12 MFMAs of 32 cycles).  bf16: 32 (a wave = 8 rows
+// = 128 pixels): a bf16 MFMA is 16 cycles for twice the k, and with 2-row waves the LDS delivers the fragments at a
+// quarter of the rate the pipe could take them (10 reads per 12 MFMAs; measured 22 % MFMA-busy) -- 11 reads per 24 now.
+int rtile_rows(bool bf16) { return bf16 ? 32 : 8; }
+
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st) {
-  if (p.NP == 48) return p.bf16 ? launch_rtile_t<3, true>(p, st, PL_GCONV_N48) : launch_rtile_t<3, false>(p, st, PL_GCONV_N48);
-  if (p.NP == 32) return p.bf16 ? launch_rtile_t<2, true>(p, st, PL_GCONV_N24) : launch_rtile_t<2, false>(p, st, PL_GCONV_N24);
+  if (p.NP == 48) return p.bf16 ? launch_rtile_t<3, 8, true>(p, st, PL_GCONV_N48) : launch_rtile_t<3, 2, false>(p, st, PL_GCONV_N48);
+  if (p.NP == 32) return p.bf16 ? launch_rtile_t<2, 8, true>(p, st, PL_GCONV_N24) : launch_rtile_t<2, 2, false>(p, st, PL_GCONV_N24);
   return hipErrorInvalidValue;
 }
 
