@@ -76,6 +76,7 @@ struct Layer {
   float* d_w16 = nullptr;
   int nch16 = 0, CGp16 = 0;
   float* d_w16s = nullptr;    // 96 -> 192 3x3 only: the 32-k step image of the 8 x 16 raw-tile kernel (se_rconv16.hip)
+  float* d_w96 = nullptr;     // 96-row stride-1 layers: the 32-k step image of se_rconv96.hip
 };
 
 // ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
@@ -358,6 +359,48 @@ int pack_rconv16(se_ctx* c, Layer& L) {
   return 0;
 }
 
+// bf16 image for rconv96_kernel (96 packed rows: 3x3 24/48 -> 96, gen_deconv 96 -> 96):
+// [class][step][6 row tiles][16 rows][32 k], k = granule (8 channels) index tap * CG + cg, four granules per step; rows in
+// the N=96 order (features, then gates); granule g of row r at slot g ^ F[r >> 2], F = {0, 2, 3, 1}.
+bool rconv96_eligible(const LayerDef& d) {
+  if (d.cout != 96 || d.stride != 1 || d.rate != 1 || d.k != 3 || d.act == ACT_NONE) return false;
+  return d.up ? d.cin == 96 : (d.cin == 48 || d.cin == 24);
+}
+int pack_rconv96(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const int F[4] = {0, 2, 3, 1};
+  const bool up2 = d.up != 0;
+  const int KW = up2 ? 2 : 3, T = KW * KW, CG = d.cin / 8, NG = T * CG, nstep = (NG + 3) / 4, ncls = up2 ? 4 : 1;
+  std::vector<unsigned short> img((size_t)ncls * nstep * 96 * 32, 0);
+  auto lo = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2); };
+  auto hi = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2); };
+  for (int cls = 0; cls < ncls; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    for (int n = 0; n < 96; ++n) {
+      const int oc = out_channel_of_row(GC_N96, n, 48, 96);
+      const int rt = n / 16, r = n % 16;
+      for (int gi = 0; gi < NG; ++gi) {
+        const int tap = gi / CG, cg = gi % CG, ty = tap / KW, tx = tap % KW, s_ = gi / 4, g = gi % 4;
+        for (int e = 0; e < 8; ++e) {
+          const int ic = cg * 8 + e;
+          float v = 0.f;
+          if (up2) {
+            for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
+              for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx) v += L.w[(((size_t)oc * d.cin + ic) * 3 + ky) * 3 + kx];
+          } else {
+            v = L.w[(((size_t)oc * d.cin + ic) * 3 + ty) * 3 + tx];
+          }
+          img[(((size_t)cls * nstep + s_) * 6 + rt) * 512 + r * 32 + ((g ^ F[r >> 2]) * 8) + e] = bf16_bits(v);
+        }
+      }
+    }
+  }
+  if (L.d_w96) (void)hipFree(L.d_w96);
+  HIPCHK(c, hipMalloc(&L.d_w96, img.size() * 2));
+  HIPCHK(c, hipMemcpy(L.d_w96, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  return 0;
+}
+
 // Winograd F(2x2,3x3) weights: U[pos] = (G g G^T)[xi][nu] per (out, in) pair, packed per position like a 1x1
 // conv Cin -> 192 (Cin = 96, or 192 for the two-source layers) in the N=192 row order (features then gates)
 // with the same slot swizzle.
@@ -532,6 +575,7 @@ int pack_net_layer(se_ctx* c, Layer& L) {
     const int rc = pack_layer16(c, L, identity_map8(d.cin));
     if (rc) return rc;
     if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && pack_rconv16(c, L)) return 1;
+    if (rconv96_eligible(d) && pack_rconv96(c, L)) return 1;
   }
   std::vector<int> m;
   if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
@@ -614,6 +658,23 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
     set_launch_cost(alg, 2.0 * 2.0 * (double)B * Hin * Win * 96, d.name, 2.0 * (double)B * Hin * Win * 192.0 * (small ? 864.0 : 896.0));
     HIPCHK(c, launch_rconv16(rp, c->st));
+    return 0;
+  }
+  // 96-row stride-1 layers (3x3 48/24 -> 96, gen_deconv 96 -> 96): raw-tile form, se_rconv96.hip (SE_RCONV96=0: gather-GEMM)
+  static const bool use_rconv96 = !(getenv("SE_RCONV96") && atoi(getenv("SE_RCONV96")) == 0);
+  if (use_rconv96 && !c->low_latency && L.d_w96 && !src1 && C0 == d.cin && Hin >= 12 && Win >= 12 &&
+      (long long)B * Ho * Wo * 96 < (1ll << 31) && (long long)B * Hin * Win * C0 * 2 < (1ll << 31)) {
+    RConv96Params rp;
+    memset(&rp, 0, sizeof rp);
+    rp.src = src0; rp.wpk = L.d_w96; rp.bias = L.d_b; rp.dst = dst;
+    rp.B = B; rp.h = Hin; rp.w = Win; rp.CG = C0 / 8;
+    rp.ty = (Hin + 15) / 16; rp.tx = (Win + 15) / 16;
+    rp.up2 = d.up ? 1 : 0; rp.act = d.act; rp.xcd = xcd_remap_enabled();
+    const int T = d.up ? 4 : 9, nstep = (T * rp.CG + 3) / 4;
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 2.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * 48), d.name,
+                    2.0 * (double)B * Hin * Win * (d.up ? 4.0 : 1.0) * 96.0 * (nstep * 32.0));
+    HIPCHK(c, launch_rconv96(rp, c->st));
     return 0;
   }
   {
@@ -1175,6 +1236,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_ub) (void)hipFree(kv.second.d_ub);
       if (kv.second.d_w16) (void)hipFree(kv.second.d_w16);
       if (kv.second.d_w16s) (void)hipFree(kv.second.d_w16s);
+      if (kv.second.d_w96) (void)hipFree(kv.second.d_w96);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
@@ -1506,6 +1568,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
     if (!rc) rc = pack_layer(c, L, identity_map(CinT));
     if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
     if (!rc && bf && k == 3 && stride == 1 && !upsample && CinT == 96 && Cout == 192 && !Cin1) rc = pack_rconv16(c, L);
+    if (!rc && bf && !Cin1 && rconv96_eligible(L.def)) rc = pack_rconv96(c, L);
     if (!rc) {
       int Ho, Wo;
       c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
@@ -1525,6 +1588,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_ub) (void)hipFree(L.d_ub);
   if (L.d_w16) (void)hipFree(L.d_w16);
   if (L.d_w16s) (void)hipFree(L.d_w16s);
+  if (L.d_w96) (void)hipFree(L.d_w96);
   return rc;
 }
 

@@ -133,6 +133,22 @@ hipError_t launch_rconv16(const RConvParams& p, hipStream_t st);
 bool rconv16_small_tiles();   // 8 x 16 tiles, two workgroups per CU (default) / SE_RCONV16_TILE=16
 
 // ---------------------------------------------------------------------------------------------
+// Raw-tile form of the 96-row bf16 gated convs, stride 1 (se_rconv96.hip): 3x3 48 -> 96 / 24 -> 96, gen_deconv 96 -> 96
+struct RConv96Params {
+  const void* src;     // bf16 NHWC [B][h][w][8 CG]
+  const void* wpk;     // bf16 image of pack_rconv96: [class][step][6 row tiles][16 rows][32 k]
+  const float* bias;   // [96] packed-row order (48 features, then 48 gates)
+  void* dst;           // bf16 NHWC [B][h][w][48], or [B][2h][2w][48] for gen_deconv
+  int B, h, w;         // source size
+  int CG;              // 8-channel granules per source pixel (3, 6, 12)
+  int ty, tx;          // 16 x 16 tiles of the source grid
+  int up2;             // gen_deconv: four 2x2 sub-pixel classes
+  int act;             // 0 ELU, 1 ReLU
+  int xcd;             // 1: XCD-aware tile order
+};
+hipError_t launch_rconv96(const RConv96Params& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
 // Raw-tile form of the narrow (MIXED-row) stride-1 gated convs, fp32 and bf16 (se_rtile.hip)
 // ---------------------------------------------------------------------------------------------
 struct RTileParams {

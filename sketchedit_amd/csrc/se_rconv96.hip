@@ -1,0 +1,197 @@
+// bf16 gated convolutions with 96 packed rows (48 features + 48 gates), stride 1, rate 1, in "raw tile" form:
+//   * 3x3, 48 -> 96 (conv3, conv14, ... at the half-resolution level) and 24 -> 96 (xconv3, pmconv3),
+//   * gen_deconv 96 -> 96 (nearest x2 + 3x3) as its four 2x2 sub-pixel classes on the source grid.
+// The structure is that of rconv16b_kernel (se_rconv16.hip -- read that header first): the input tile of a 16 x 16 block
+// of outputs with its halo is DMA'd into LDS once, pixel-major, and every tap's B fragments are read straight from it;
+// the weights stream in 32-k steps ([class][step][6 row tiles][16 rows][32 k], pack_rconv96 in se_api.hip) through a ring
+// of three 6 KB slots; 4 waves, each all 96 rows x 64 pixels (4 tile rows), so the gate is a register epilogue;
+// 49 - 73 KB of LDS: two workgroups per CU.  The gather-GEMM these layers ran on staged every pixel 9 (4) times and sat
+// at 23 % MFMA-busy.
+// k order: granule (8 channels) gi = tap * CG + cg; a 32-k step is 4 consecutive granules and may straddle two taps
+// (CG = 6, 3): the per-lane raw-tile offset of every step is computed once, before the loop.
+// LDS layout of the raw tile: pixel stride P granules.  CG = 12: P = 12 with the XOR-2 swizzle of rconv16; CG = 6: P = 6,
+// natural (1.04 average conflict degree over the steps); CG = 3: P = 6, three zero granules per pixel (1.36; natural P = 3
+// gives 1.93) -- exhaustive evaluation over the 16-lane groups of ds_read_b128.
+// Reference semantics: gen_conv / gen_deconv, /root/reference/models/networks/utils.py:9-51; rounding points of the bf16
+// mode: oracle/sketchedit_oracle.py.
+#include "se_device.h"
+
+#include <cstdlib>
+
+namespace se {
+
+template <int CG, int P, int KW, bool UP>
+__global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) {
+  constexpr int TS = 16, RS = TS + KW - 1;            // tile side, raw (halo) tile side
+  constexpr int PIXB = P * 16, ROWB = RS * PIXB;
+  constexpr int SLOTS = RS * RS * P;
+  constexpr int NDMA = (SLOTS + 63) / 64;
+  constexpr int RAWB = NDMA * 1024;
+  constexpr int WSB = 6 * 1024;                       // one 32-k weight step: 6 row tiles of 1 KB
+  constexpr int T = KW * KW, NG = T * CG, NSTEP = (NG + 3) / 4, NS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Raw = smem;
+  char* Wb = smem + RAWB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.B * p.ty * p.tx;
+  int tile, cls = 0;
+  if (UP) {
+    if (!class_tile((int)blockIdx.x, ntiles, p.xcd, tile, cls)) return;
+  } else {
+    tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  }
+  const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
+  const int ty0 = (t2 / p.tx) * TS, tx0 = (t2 % p.tx) * TS;
+  const int py = cls >> 1, px = cls & 1;
+  const int pady = UP ? 1 - py : 1, padx = UP ? 1 - px : 1;
+
+  const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.h * p.w * (unsigned)(CG * 16));
+  const unsigned lds_raw = lds_addr_of(Raw), lds_w = lds_addr_of(Wb);
+  const char* wsrc = (const char*)p.wpk + (size_t)cls * NSTEP * WSB;
+  // weight step s: row tiles w and w + 4 (waves 0, 1 issue two DMAs per step, waves 2, 3 one)
+  auto dma_w = [&](int s, int j) {
+    const int rt = j * 4 + w;
+    if (rt < 6) glds16_s(wsrc + (size_t)s * WSB + rt * 1024, (unsigned)lane * 16u, lds_w + (s % NS) * WSB + rt * 1024);
+  };
+  auto wait_newest_step = [&]() {                     // everything but the DMAs of the most recently issued weight step
+    if (w < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  };
+  // ---- prologue: weight step 0, the raw tile, weight step 1 (in this order: the counted waits rely on it)
+  dma_w(0, 0); dma_w(0, 1);
+#pragma unroll
+  for (int i0 = 0; i0 < (NDMA + 3) / 4; ++i0) {
+    const int i = i0 * 4 + w;
+    if (i < NDMA) {
+      const int q = i * 64 + lane;                   // granule slot of the raw tile
+      const int pix = q / P, gs = q - pix * P;
+      const int row = pix / RS, c = pix - row * RS;
+      const int gl = CG == 12 ? gs ^ (((c >> 2) & 1) << 1) : gs;     // stored slot gs holds logical granule gl
+      const int sy = ty0 - pady + row, sx = tx0 - padx + c;
+      const bool ok = q < SLOTS && gs < CG && (unsigned)sy < (unsigned)p.h && (unsigned)sx < (unsigned)p.w;
+      const unsigned off = (unsigned)((b * p.h + sy) * p.w + sx) * (unsigned)(CG * 16) + (unsigned)gl * 16u;
+      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);      // outside the image / pad granule: zero fill
+    }
+  }
+  if (NSTEP > 1) { dma_w(1, 0); dma_w(1, 1); }
+
+  // per-lane raw-tile offset of each step: lane (j = lane & 15, g4 = lane >> 4) reads granule gi = 4 s + g4
+  const int jx = lane & 15, g4 = lane >> 4;
+  int boff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int gi = min(s * 4 + g4, NG - 1);          // K padding (zero weights): any valid address
+    const int tap = gi / CG, cg = gi - tap * CG;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    const int c = jx + kx;
+    const int slot = CG == 12 ? cg ^ (((c >> 2) & 1) << 1) : cg;
+    boff[s] = ky * ROWB + c * PIXB + slot * 16;
+  }
+  const int pg = w;                                   // wave = all 96 rows x tile rows 4 pg .. 4 pg + 3
+  constexpr int NTW = 6, PT = 4;
+  const int rq = (lane & 15) >> 2;
+  const int aoff = (lane & 15) * 64 + (((lane >> 4) ^ ((0x78 >> (rq * 2)) & 3)) << 4);      // swizzle F = {0,2,3,1}[row >> 2]
+
+  f32x4 acc[NTW][PT];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto bfrag = [&](int s, int pt) -> bf16x8 { return *(const bf16x8*)(Raw + (4 * pg + pt) * ROWB + boff[s]); };
+  auto afrag = [&](int s, int i) -> bf16x8 { return *(const bf16x8*)(Wb + (s % NS) * WSB + aoff + i * 1024); };
+  if (NSTEP > 1) wait_newest_step();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bf16x8 xb[PT], xn[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) xb[pt] = bfrag(0, pt);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {       // fully unrolled: ring slots and register rotation are compile-time
+    constexpr int DEPTH = 3;
+    bf16x8 wq[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) wq[u] = afrag(s, u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+      const bf16x8 wa = wq[u % DEPTH];
+      if (u + DEPTH < NTW) wq[u % DEPTH] = afrag(s, u + DEPTH);
+      if (u >= 1 && u < 1 + PT && s + 1 < NSTEP) xn[u - 1] = bfrag(s + 1, u - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        acc[u][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[pt], acc[u][pt], 0, 0, 0);
+      // weight step s + 2 goes to the slot step s - 1 has left (everyone passed the barrier that ended it)
+      if (u < 2 && s + 2 < NSTEP) dma_w(s + 2, u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) xb[pt] = xn[pt];
+    if (s + 2 < NSTEP) wait_newest_step();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, gate, transposed through LDS (the raw tile's room), 16-byte stores: 6 pieces per pixel
+  constexpr int OPX = 112;
+  const int q = lane >> 4;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    char* o = Raw + ((4 * pg + pt) * 16 + jx) * OPX;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const int c0 = nt * 16 + q * 4;
+      const f32x4 bf = *(const f32x4*)(p.bias + c0);
+      const f32x4 bg = *(const f32x4*)(p.bias + 48 + c0);
+      float ov[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float f = acc[nt][pt][r] + bf[r];
+        const float g = acc[nt + 3][pt][r] + bg[r];
+        ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
+      }
+      *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
+    }
+  }
+  __syncthreads();
+  const int OW = UP ? 2 * p.w : p.w, OH = UP ? 2 * p.h : p.h;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {                  // 256 pixels x 6 pieces of 16 bytes = 6 per thread
+    const int piece = it * 256 + tid;
+    const int pix = piece / 6, part = piece - pix * 6;
+    const int sy = ty0 + (pix >> 4), sx = tx0 + (pix & 15);
+    if (sy < p.h && sx < p.w) {
+      const int oy = UP ? 2 * sy + py : sy, ox = UP ? 2 * sx + px : sx;
+      *(uint4*)((char*)p.dst + ((size_t)(b * OH + oy) * OW + ox) * 96 + part * 16) = *(const uint4*)(Raw + pix * OPX + part * 16);
+    }
+  }
+}
+
+template <int CG, int P, int KW, bool UP>
+static hipError_t launch_rconv96_t(const RConv96Params& p, hipStream_t st) {
+  constexpr int RS = 16 + KW - 1;
+  constexpr int RAWB = ((RS * RS * P + 63) / 64) * 1024;
+  static_assert(RAWB >= 256 * 112, "the epilogue transposes the gated tile in the raw tile's room");
+  constexpr int LDS = RAWB + 3 * 6 * 1024;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  hipError_t e = ensure_max_lds((const void*)rconv96_kernel<CG, P, KW, UP>, LDS);
+  if (e != hipSuccess) return e;
+  const int tiles = p.B * p.ty * p.tx;
+  const int grid = UP ? class_tile_grid(tiles) : tiles;
+  set_launch_grid(grid);
+  ProfScope ps_(st, PL_GCONV_N96);
+  hipLaunchKernelGGL((rconv96_kernel<CG, P, KW, UP>), dim3(grid), dim3(256), LDS, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_rconv96(const RConv96Params& p, hipStream_t st) {
+  if (p.up2) return p.CG == 12 ? launch_rconv96_t<12, 12, 2, true>(p, st) : hipErrorInvalidValue;
+  if (p.CG == 6) return launch_rconv96_t<6, 6, 3, false>(p, st);
+  if (p.CG == 3) return launch_rconv96_t<3, 6, 3, false>(p, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace se

@@ -101,6 +101,29 @@ def test_op_rconv16_raw_tile_bf16(eng, case):
     _layer_close(y, O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act, BF))
 
 
+RCONV96 = [(48, False, 16, 16, "elu"), (48, False, 22, 18, "elu"), (48, False, 40, 33, "relu"), (24, False, 22, 18, "elu"),
+           (24, False, 32, 48, "elu"), (96, True, 16, 16, "elu"), (96, True, 22, 18, "elu"), (96, True, 12, 35, "elu")]
+
+
+@pytest.mark.parametrize("case", RCONV96, ids=["c%d-u%d-%dx%d-%s" % c for c in RCONV96])
+def test_op_rconv96_raw_tile_bf16(eng, case):
+    """The 96-row stride-1 layers in the raw-tile form (se_rconv96.hip): 3x3 48 -> 96 (a 32-k step straddles two taps),
+    24 -> 96 (padded pixel stride), gen_deconv 96 -> 96 (sub-pixel classes); exact and ragged 16x16 tiles, image borders."""
+    from oracle import sketchedit_oracle as O
+    cin, up, H, W, act = case
+    a = 1.5 / np.sqrt(cin * 9)
+    w = synth.uniform(43, "r96.w%s" % (case,), (96, cin, 3, 3), -a, a)
+    b = synth.uniform(43, "r96.b%s" % (case,), (96,), -0.3, 0.3)
+    x = synth.uniform(43, "r96.x%s" % (case,), (2, cin, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=1, act=act, upsample=up, bf16=True)
+    tw, tb, tx = torch.from_numpy(w), torch.from_numpy(b), torch.from_numpy(x)
+    if up:
+        ref = O.gated_deconv(tx, tw, tb, BF)       # pre-summed sub-pixel weights are rounded once (see above)
+        assert float(np.abs(_np(y) - _np(ref)).max()) < 2e-2
+    else:
+        _layer_close(y, O.gated_conv(tx, tw, tb, 1, 1, act, BF))
+
+
 @pytest.mark.parametrize("kind", ["tensor", "vector"])
 def test_op_two_source_conv_bf16(eng, kind):
     from oracle import sketchedit_oracle as O
