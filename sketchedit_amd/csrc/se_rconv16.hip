@@ -1,8 +1,8 @@
 // bf16 gated convolution 96 -> 192, 3x3, stride 1, any dilation -- "raw tile" form (BASELINE config 5).
 //
 // The gather-GEMM of se_gconv.hip stages an im2col image: every input pixel enters LDS once per tap (9x) and the
-// [192][64-k] weight tile once per 128 output pixels.  On the bf16 pipe that kernel is bound by the LDS fill (measured:
-// ~19 B/clk/CU of LDS-DMA, MFMA pipe 36 % busy), so this kernel cuts the bytes that are staged:
+// [192][64-k] weight tile once per 128 output pixels.  On the bf16 pipe that kernel spends its issue slots on staging
+// (~19 B/clk/CU of LDS-DMA from inside the MFMA loop, MFMA pipe 36 % busy), so this kernel cuts the bytes that are staged:
 //   * the input tile of a 16 x 16 block of outputs (18 x 18 pixels with the halo, all 96 channels, 61 KB) is DMA'd into
 //     LDS ONCE in its natural pixel-major layout, and the MFMA B fragments of all 9 taps are read straight from it -- a
 //     tap is an address offset, nothing is re-staged;

@@ -1,10 +1,11 @@
 // Narrow gated convolutions (24 or 12 gated output channels: the 5x5 first layers, the 48 -> 48 gen_deconv, the 24 -> 24
 // layers -- all at full or half image resolution) in "raw tile" form, fp32 and bf16.
 //
-// On these layers the gather-GEMM of se_gconv.hip is bound by the LDS fill, not by the MFMA pipe: its im2col image
+// On these layers the gather-GEMM of se_gconv.hip is held back by its staging, not by the MFMA pipe: its im2col image
 // stages every input pixel once per tap (9x, 25x for the 5x5 layers) -- 16 KB of pixels + 6 KB of weights per 32-k chunk
-// and 128 outputs against 1536 cycles of fp32 MFMAs, i.e. 28.6 B/clk for two resident workgroups where the CU's LDS-DMA
-// sustains about 19 B/clk: the pipe sits at 65 % (profiles/r02_c2_pmc_summary.txt).  Here
+// and 128 outputs against 1536 cycles of fp32 MFMAs, i.e. 28.6 B/clk for two resident workgroups, issued from inside the
+// MFMA loop (which sustained about 19 B/clk; the DMA path alone does 33 - 57, tools/ubench/lds_fill_rate.hip): the pipe
+// sat at 65 %.  Here
 //   * the input tile of an 8 x 16 (fp32) / 32 x 16 (bf16) block of outputs (with its halo, every channel) is DMA'd into
 //     LDS ONCE, pixel-major,
 //     and the B fragments of every tap are read straight from it (a tap is an address offset);
