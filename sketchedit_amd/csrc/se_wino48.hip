@@ -46,8 +46,9 @@ extern "C" int se_debug_wino48_trace(unsigned long long* host_out) {
 
 namespace se {
 
-__global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
-  constexpr int TILES = 128;
+template <int TILES>
+__global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p) {
+  constexpr int NTHR = TILES * 4, NWV = TILES / 16;      // one thread per staged granule; a wave per (row half, 32 tiles)
   constexpr int XB = TILES * 128, WB = 96 * 128;
   constexpr int NIT = 24;              // 8 position pairs x 3 chunks
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   // Source offsets of the 4x4 input tile, kept in LDS (read once per position):
   //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or -1 if outside / invalid tile
   //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
-  int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
-  int* Xsrc = Ysrc + 4 * 512;
+  int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);     // 8 * NTHR ints
+  int* Xsrc = Ysrc + 4 * NTHR;
   {
     const int t = tile_base + srow;
     int b, y0, x0;
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
-      Ysrc[i * 512 + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : -1;
-      Xsrc[i * 512 + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
+      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : -1;
+      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   auto set_pos = [&](int set, int pos) {    // compile-time arguments after unrolling
     const int xi = pos >> 2, nu = pos & 3;
     // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * 512 + tid], yb = Ysrc[(xi == 3 ? 3 : 2) * 512 + tid];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * 512 + tid], xb = Xsrc[(nu == 3 ? 3 : 2) * 512 + tid];
+    const int ya = Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = Ysrc[(xi == 3 ? 3 : 2) * NTHR + tid];
+    const int xa = Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = Xsrc[(nu == 3 ? 3 : 2) * NTHR + tid];
     const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = yb < 0 ? 0.f : ((xi == 0 || xi == 3) ? -1.f : 1.f);
     const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = xb < 0 ? 0.f : ((nu == 0 || nu == 3) ? -1.f : 1.f);
     // always load from a valid (clamped) address; the padding zero is applied through the factor
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
     *(f32x4*)(xw0 + buf * XB) = v0;
     *(f32x4*)(xw1 + buf * XB) = v1;
   };
-  // W tile: 12 row blocks of 8 rows; wave w stages block w, and block 8 + w if w < 4
+  // W tile: 12 row blocks of 8 rows; wave w stages blocks w, w + NWV, ... (8 waves: 2 calls, 4 waves: 3 calls per tile)
   auto dma_w = [&](int it, int buf, int j) {
-    const int rbk = j * 8 + w;
+    const int rbk = j * NWV + w;
     if (rbk < 12) glds16_s(p.upk + (size_t)it * 96 * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WB + rbk * 1024);
   };
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   set_pos(0, 0);
   set_pos(1, 1);
 #pragma unroll
-  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); }     // W DMA first: overlaps the granule round trip
+  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); if (NWV < 8) dma_w(i0, i0, 2); }     // W DMA first: overlaps the granule round trip
   {
     f32x4 r1[2][4];                    // iterations 0 and 1: both sets of loads in flight before the first transform
 #pragma unroll
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
     if (more3) { dma_w(it + 3, w3, 1); load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 2, false);
-    if (more3) { load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
+    if (more3) { if (NWV < 8) dma_w(it + 3, w3, 2); load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 3, false);
     if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
@@ -325,17 +326,24 @@ __global__ __launch_bounds__(512, 2) void wino48_kernel(const WinoParams p) {
   W48_TRACE_DUMP();
 }
 
-hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 8 * 512 * 4 + (W48_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 48 KB + W ring 48 KB + source offsets
+// 64 tiles / 4 waves / 80 KB per workgroup (default): two workgroups share a CU, one's prologue, fold and epilogue run
+// under the other's MFMAs.  SE_WINO48_TILES=128 selects the 8-wave, one-workgroup-per-CU shape of round 1.
+template <int TILES>
+static hipError_t launch_wino48_t(const WinoParams& p, hipStream_t st) {
+  constexpr int LDS = 3 * TILES * 128 + 4 * 96 * 128 + 8 * TILES * 4 * 4 + (W48_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring + W ring 48 KB + source offsets
   {
-    hipError_t e = ensure_max_lds((const void*)wino48_kernel, LDS);
+    hipError_t e = ensure_max_lds((const void*)wino48_kernel<TILES>, LDS);
     if (e != hipSuccess) return e;
   }
-  const int grid = (p.total_tiles + 127) / 128;
+  const int grid = (p.total_tiles + TILES - 1) / TILES;
   set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_N96);
-  hipLaunchKernelGGL(wino48_kernel, dim3(grid), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL(wino48_kernel<TILES>, dim3(grid), dim3(TILES * 4), LDS, st, p);
   return hipGetLastError();
+}
+hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
+  static const bool big = W48_TRACE_LDS || (getenv("SE_WINO48_TILES") && atoi(getenv("SE_WINO48_TILES")) == 128);
+  return big ? launch_wino48_t<128>(p, st) : launch_wino48_t<64>(p, st);
 }
 
 }  // namespace se
