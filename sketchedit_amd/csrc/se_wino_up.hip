@@ -17,8 +17,9 @@
 
 namespace se {
 
-__global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
-  constexpr int TILES = 128;
+template <int TILES>
+__global__ __launch_bounds__(TILES * 4, 2) void winoup_kernel(const WinoParams p) {
+  constexpr int NTHR = TILES * 4, NWV = TILES / 16;
   constexpr int XB = TILES * 128, WB = 96 * 128;
   constexpr int NIT = 27;              // 9 positions x 3 chunks
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
   //   Ysrc[i][tid] = byte offset of source row yy0 - 1 + py + i (+ this lane's granule), or -1 if outside / invalid tile
   //   Xsrc[i][tid] = byte offset of source column xx0 - 1 + px + i inside the row, or -1 if outside
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
-  int* Xsrc = Ysrc + 3 * 512;
+  int* Xsrc = Ysrc + 3 * NTHR;
   {
     const int t = tile_base + srow;
     int b, y0, x0;
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int y = y0 - 1 + py + i, x = x0 - 1 + px + i;
-      Ysrc[i * 512 + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + (unsigned)sg * 16u) : -1;
-      Xsrc[i * 512 + tid] = ((unsigned)x < (unsigned)p.w) ? x * 384 : -1;
+      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + (unsigned)sg * 16u) : -1;
+      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 384 : -1;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
   float g[4];           // their B^T factors (0 for a pixel outside the image: zero padding)
   auto set_pos = [&](int pos) {             // compile-time argument after unrolling
     const int xi = pos / 3, nu = pos % 3;
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * 512 + tid], yb = Ysrc[(xi == 2 ? 2 : 1) * 512 + tid];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * 512 + tid], xb = Xsrc[(nu == 2 ? 2 : 1) * 512 + tid];
+    const int ya = Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = Ysrc[(xi == 2 ? 2 : 1) * NTHR + tid];
+    const int xa = Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = Xsrc[(nu == 2 ? 2 : 1) * NTHR + tid];
     const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = (xi == 1 || yb < 0) ? 0.f : (xi == 0 ? -1.f : 1.f);
     const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = (nu == 1 || xb < 0) ? 0.f : (nu == 0 ? -1.f : 1.f);
     // always load from a valid (clamped) address; the padding zero is applied through the factor
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
   };
   // W tile: 12 row blocks of 8 rows; wave w stages block w, and block 8 + w if w < 4
   auto dma_w = [&](int it, int buf, int j) {
-    const int rbk = j * 8 + w;
+    const int rbk = j * NWV + w;
     if (rbk < 12) glds16_s(upk + (size_t)it * 96 * 32 + rbk * 256, (unsigned)lane * 16u, lds_w + buf * WB + rbk * 1024);
   };
 
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
   f32x4 r[2][4];
   set_pos(0);
 #pragma unroll
-  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); }     // W DMA first: overlaps the granule round trip
+  for (int i0 = 0; i0 < 3; ++i0) { dma_w(i0, i0, 0); dma_w(i0, i0, 1); if (NWV < 8) dma_w(i0, i0, 2); }     // W DMA first: overlaps the granule round trip
   {
     f32x4 r1[2][4];                    // iterations 0 and 1: both sets of loads in flight before the first transform
 #pragma unroll
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
     if (more3) { dma_w(it + 3, w3, 1); load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 2, false);
-    if (more3) { load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
+    if (more3) { if (NWV < 8) dma_w(it + 3, w3, 2); load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 3, false);
     if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
@@ -264,17 +265,23 @@ __global__ __launch_bounds__(512, 2) void winoup_kernel(const WinoParams p) {
   }
 }
 
-hipError_t launch_winoup(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 128 * 128 + 4 * 96 * 128 + 6 * 512 * 4;     // X ring 48 KB + W ring 48 KB + source offsets
+// 64 tiles / 4 waves / 78 KB per workgroup (default): two workgroups per CU (se_wino48.hip); SE_WINOUP_TILES=128: 8 waves
+template <int TILES>
+static hipError_t launch_winoup_t(const WinoParams& p, hipStream_t st) {
+  constexpr int LDS = 3 * TILES * 128 + 4 * 96 * 128 + 6 * TILES * 4 * 4;     // X ring + W ring 48 KB + source offsets
   {
-    hipError_t e = ensure_max_lds((const void*)winoup_kernel, LDS);
+    hipError_t e = ensure_max_lds((const void*)winoup_kernel<TILES>, LDS);
     if (e != hipSuccess) return e;
   }
-  const int grid = class_tile_grid((p.total_tiles + 127) / 128);
+  const int grid = class_tile_grid((p.total_tiles + TILES - 1) / TILES);
   set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_UP96);
-  hipLaunchKernelGGL(winoup_kernel, dim3(grid), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL(winoup_kernel<TILES>, dim3(grid), dim3(TILES * 4), LDS, st, p);
   return hipGetLastError();
+}
+hipError_t launch_winoup(const WinoParams& p, hipStream_t st) {
+  static const bool big = getenv("SE_WINOUP_TILES") && atoi(getenv("SE_WINOUP_TILES")) == 128;
+  return big ? launch_winoup_t<128>(p, st) : launch_winoup_t<64>(p, st);
 }
 
 }  // namespace se
