@@ -597,7 +597,14 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   *done = false;
   const LayerDef& d = L.def;
   static const bool enabled = !(getenv("SE_RTILE") && atoi(getenv("SE_RTILE")) == 0);
-  if (!enabled || c->low_latency || src1 || d.stride != 1 || d.rate != 1 || (L.cfg != GC_N48 && L.cfg != GC_N24)) return 0;
+  if (!enabled || src1 || d.stride != 1 || d.rate != 1 || (L.cfg != GC_N48 && L.cfg != GC_N24)) return 0;
+  {
+    // low-latency mode: only when the tiles still cover the CUs (the small-grid gather-GEMM splits rows over blockIdx.y)
+    const int TR0 = rtile_rows(bf);
+    const long tiles = (long)B * ((Hin + TR0 - 1) / TR0) * ((Win + 15) / 16) * (d.up ? 4 : 1);
+    static const int ll_min = getenv("SE_RTILE_LL_MIN") ? atoi(getenv("SE_RTILE_LL_MIN")) : 256;
+    if (c->low_latency && tiles < ll_min) return 0;
+  }
   const int es = bf ? 2 : 4, gran = bf ? 8 : 4;
   const int CG = bf ? L.CGp16 : L.CGp, nch = bf ? L.nch16 : L.nch;
   const float* wimg = bf ? L.d_w16 : L.d_w;
