@@ -228,7 +228,7 @@ hipError_t launch_pack_g16(const float* x, const float* x2, const float* mask, c
                            float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint, hipStream_t st);
 hipError_t launch_nchw_to_nhwc16(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st);
 hipError_t launch_nhwc16_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st);
-static const int COLREDUCE_SPLITS = 32;
+static const int COLREDUCE_SPLITS = 128;
 
 // ---------------------------------------------------------------------------------------------
 // Contextual attention (patch 4, stride 2)

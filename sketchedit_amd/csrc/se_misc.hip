@@ -387,30 +387,51 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int C
 template <bool BF16>
 __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                                 int HW, int C, int op) {
-  // grid (SPLITS, B); block 256 threads = (256/C' groups) ... generic: thread t handles channel t%C, pixel lane t/C
-  __shared__ float red[256];
+  // grid (SPLITS, B).  A thread owns one 16-byte granule of channels (4 fp32 / 8 bf16) and walks the split's pixels
+  // `groups` apart, four loads in flight; the groups are then combined through LDS in a fixed order (deterministic).
+  constexpr int V = BF16 ? 8 : 4;
+  __shared__ float red[256 * V];
   const int b = blockIdx.y, sp = blockIdx.x;
   const int per = (HW + COLREDUCE_SPLITS - 1) / COLREDUCE_SPLITS;
   const int p0 = sp * per, p1 = min(HW, p0 + per);
-  const int groups = 256 / C;            // C <= 256
-  const int c = threadIdx.x % C, g = threadIdx.x / C;
-  float a = op == 0 ? -INFINITY : 0.f;
-  if (g < groups) {
-    for (int pp = p0 + g; pp < p1; pp += groups) {
-      const float v = BF16 ? __uint_as_float((unsigned)((const unsigned short*)x)[((long)b * HW + pp) * C + c] << 16)
-                           : x[((long)b * HW + pp) * C + c];
-      a = op == 0 ? fmaxf(a, v) : (op == 1 ? a + v : fmaf(v, v, a));
+  const int CV = C / V;                  // granules per pixel (C % V == 0, CV <= 256: checked by the launcher)
+  const int groups = 256 / CV;
+  const int cv = threadIdx.x % CV, g = threadIdx.x / CV;
+  float a[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) a[e] = op == 0 ? -INFINITY : 0.f;
+  auto acc = [&](const uint4 u) {
+    float v[V];
+    if (BF16) {
+      v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
+      if (V == 8) { v[4] = bf16_lo(u.z); v[5] = bf16_hi(u.z); v[6] = bf16_lo(u.w); v[7] = bf16_hi(u.w); }
+    } else {
+      v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
     }
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = op == 0 ? fmaxf(a[e], v[e]) : (op == 1 ? a[e] + v[e] : fmaf(v[e], v[e], a[e]));
+  };
+  if (g < groups) {
+    const uint4* row = (const uint4*)x + (long)b * HW * CV + cv;
+    int pp = p0 + g;
+    for (; pp + 3 * groups < p1; pp += 4 * groups) {
+      const uint4 u0 = row[(long)pp * CV], u1 = row[(long)(pp + groups) * CV], u2 = row[(long)(pp + 2 * groups) * CV],
+                  u3 = row[(long)(pp + 3 * groups) * CV];
+      acc(u0); acc(u1); acc(u2); acc(u3);
+    }
+    for (; pp < p1; pp += groups) acc(row[(long)pp * CV]);
   }
-  red[threadIdx.x] = a;
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[threadIdx.x * V + e] = a[e];
   __syncthreads();
-  if (threadIdx.x < C) {
-    float r = red[threadIdx.x];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int cv2 = c / V, e = c - cv2 * V;
+    float r = red[cv2 * V + e];
     for (int gg = 1; gg < groups; ++gg) {
-      const float v = red[gg * C + threadIdx.x];
+      const float v = red[(gg * CV + cv2) * V + e];
       r = op == 0 ? fmaxf(r, v) : r + v;
     }
-    partial[((long)b * COLREDUCE_SPLITS + sp) * C + threadIdx.x] = r;
+    partial[((long)b * COLREDUCE_SPLITS + sp) * C + c] = r;
   }
 }
 __global__ void colreduce_final_kernel(const float* __restrict__ partial, float* __restrict__ out, unsigned short* out16,
@@ -430,7 +451,7 @@ __global__ void colreduce_final_kernel(const float* __restrict__ partial, float*
 }
 hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st,
                             int x_bf16, float* out_bf16) {
-  if (C > 256) return hipErrorInvalidValue;
+  if (C > 256 || C % (x_bf16 ? 8 : 4)) return hipErrorInvalidValue;
   ProfScope ps_(st, PL_COLREDUCE);
   if (x_bf16) hipLaunchKernelGGL(colreduce_partial_kernel<true>, dim3(COLREDUCE_SPLITS, B), dim3(256), 0, st, x, partial, HW, C, op);
   else hipLaunchKernelGGL(colreduce_partial_kernel<false>, dim3(COLREDUCE_SPLITS, B), dim3(256), 0, st, x, partial, HW, C, op);
