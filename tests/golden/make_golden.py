@@ -178,9 +178,44 @@ def op_cases():
     return out
 
 
+FACE = "/root/reference/datasets/face_release/%s/602_images_celeb_00033.png"
+
+
+def face_case(m):
+    """BASELINE config 1 (test_celeb.sh): the bundled 256x256 face and its sketch, batch 1, through the reference.
+    Inputs as /root/reference/data/testimage_dataset.py:89-111 builds them (ToTensor + Normalize(0.5, 0.5); sketch 'L',
+    > 0); outputs also as test.py:25-27 quantises them.  The fixture carries the two input images as uint8 arrays (data,
+    not code) so that the GPU box needs nothing from /root/reference."""
+    from PIL import Image
+    image = Image.open(FACE % "images").convert("RGB")
+    w, h = image.size
+    sketch = Image.open(FACE % "edges").convert("L").resize((w, h))
+    iu8, su8 = np.asarray(image, np.uint8), np.asarray(sketch, np.uint8)
+    img = torch.from_numpy(((iu8.astype(np.float32).transpose(2, 0, 1) / 255.0) - 0.5) / 0.5)[None]
+    sk = torch.from_numpy((su8.astype(np.float32)[None, None] / 255.0 > 0).astype(np.float32))
+    with torch.no_grad():
+        composed, soft = m({"image": img, "mask": sk, "gt": img, "edgegt": sk}, mode="inference")
+        hard = (soft > 0.5).float()
+        coarse, fine = m.netG(img, img, hard, hard, sk)
+    out = {"image_u8": iu8, "sketch_u8": su8,
+           "composed_u8": ((composed + 1) / 2 * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0),     # test.py:25-35 (HWC, RGB)
+           "mask_u8": (soft * 255).numpy().astype(np.uint8)[0, 0],
+           "hard_mask_bits": np.packbits(hard.numpy().astype(np.uint8))}
+    for k, v in (("composed", composed), ("mask", soft), ("coarse", coarse), ("fine", fine)):
+        out[k + "_sum"] = summary(v.numpy())
+        out[k + "_crop"] = v.numpy()[:, :, 96:160, 96:160].astype(np.float32)
+    print("face: sketch density %.4f  hole fraction %.3f  mask range [%.3f, %.3f]" % (
+        float(sk.mean()), float(hard.mean()), float(soft.min()), float(soft.max())))
+    return out
+
+
 def main():
     gain = synth.DEFAULT_GAIN
     m = build_reference(gain)
+    if "--only-face" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "c1_face.npz"), meta=np.array([gain, 0], np.float64), **face_case(m))
+        print("c1_face.npz %.1f KB" % (os.path.getsize(os.path.join(HERE, "c1_face.npz")) / 1024))
+        return
     # ---- 64x64, B=2: full tensors --------------------------------------------------
     small = run_case(m, 2, 64, 64, seed=1234)
     hf = float(small["hard_mask"].mean())
@@ -229,6 +264,8 @@ def main():
     print("bf16 64x64: |composed - fp32| max %.4f  hard-mask flips vs fp32 %d" % (
         np.abs(b16["composed"] - small["composed"]).max(), int((b16["hard_mask"] != small["hard_mask"]).sum())))
     np.savez_compressed(os.path.join(HERE, "e2e_64_bf16.npz"), meta=np.array([gain, 0, 1234, 2, 64, 64], np.float64), **b16)
+    # ---- BASELINE config 1: the bundled face sample --------------------------------
+    np.savez_compressed(os.path.join(HERE, "c1_face.npz"), meta=np.array([gain, 0], np.float64), **face_case(m))
     # ---- per-op known answers ------------------------------------------------------
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **op_cases())
     for f in sorted(os.listdir(HERE)):

@@ -234,6 +234,39 @@ def test_test_py_script_end_to_end(tmp_path):
             assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
+def test_celeb_sample_through_test_py_matches_the_reference(tmp_path, golden_dir):
+    """BASELINE config 1: test_celeb.sh's command line (batch 1) on the reference's bundled face + sketch -- written
+    back to PNG files from the fixture -- gives the PNGs the reference produces (fixture: tests/golden/make_golden.py)."""
+    import importlib.util
+    from PIL import Image
+    g = dict(np.load(os.path.join(golden_dir, "c1_face.npz")))
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    Image.fromarray(g["image_u8"]).save(tmp_path / "images" / "face.png")
+    Image.fromarray(g["sketch_u8"]).save(tmp_path / "edges" / "face.png")
+    (tmp_path / "list.txt").write_text("face.png\n")
+    argv = ("--batchSize 1 --nThreads 1 --name celeb --joint_train_inp --dataset_mode testimage --image_dirs {d}/images "
+            "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
+            "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --output_dir {d}/results "
+            "--output_mask_dir {d}/masks --synthetic_weights").format(d=tmp_path).split()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_test_script_c1", os.path.join(root, "test.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(argv)
+    out = np.asarray(Image.open(tmp_path / "results" / "face.png"))
+    msk = np.asarray(Image.open(tmp_path / "masks" / "face.png"))
+    dm = np.abs(msk.astype(int) - g["mask_u8"].astype(int))
+    assert dm.max() <= 1 and (dm > 0).mean() < 0.01
+    hard = np.unpackbits(g["hard_mask_bits"])[:256 * 256].reshape(256, 256)
+    flips = int(((msk > 127) != (g["mask_u8"] > 127)).sum())
+    assert flips <= 2
+    if flips == 0:
+        d = np.abs(out.astype(int) - g["composed_u8"].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+    assert hard.mean() > 0.1
+
+
 def test_module_prefixed_checkpoint_through_the_c_abi(golden_dir):
     """A DataParallel-style state dict ('module.' prefix, util/util.py:221-222) loaded straight through se_load_weights
     gives the reference's vectors; a truncated dict leaves the engine not ready."""

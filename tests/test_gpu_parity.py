@@ -328,6 +328,24 @@ def test_inference_256_golden(eng_w, golden_dir, mode):
         np.testing.assert_allclose(s, g[k + "_sum"], rtol=2e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("mode", MODES[:2], ids=[m[0] for m in MODES[:2]])
+def test_inference_c1_bundled_face_golden(eng_w, golden_dir, mode):
+    """BASELINE config 1: the reference's bundled 256x256 face and sketch (0.34 % dense), batch 1, against the reference's
+    own outputs on them (tests/golden/c1_face.npz), in the default and the low-latency execution mode."""
+    g = _load(golden_dir, "c1_face.npz")
+    img = ((g["image_u8"].astype(np.float32).transpose(2, 0, 1) / 255.0) - 0.5) / 0.5
+    sk = (g["sketch_u8"].astype(np.float32)[None, None] / 255.0 > 0).astype(np.float32)
+    r = eng_w.inference(_cuda(img[None]), _cuda(sk), FLAGS, visualize=True, **mode[1])
+    hard = r["hard"].cpu().numpy()
+    ref_hard = np.unpackbits(g["hard_mask_bits"])[: hard.size].reshape(hard.shape).astype(np.float32)
+    assert int((hard != ref_hard).sum()) == 0
+    for k in ("composed", "mask", "coarse", "fine"):
+        assert _md(r[k][:, :, 96:160, 96:160], g[k + "_crop"]) < TOL_E2E, k
+        a = r[k].double().cpu().numpy()
+        s_ = np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.min(), a.max()])
+        np.testing.assert_allclose(s_, g[k + "_sum"], rtol=2e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("ll", [False, True], ids=["default", "lowlat"])
 def test_batch_shard_invariance(eng_w, ll):
     """Image k gives the same result whichever batch (position) computes it -- the property the

@@ -117,6 +117,31 @@ def test_e2e_256(golden_dir):
         np.testing.assert_allclose(_summary(out[k]), g[k + "_sum"], rtol=2e-5, atol=2e-4)
 
 
+def _face_inputs(g):
+    """The tensors /root/reference/data/testimage_dataset.py:89-111 builds from the two bundled images."""
+    img = torch.from_numpy(((g["image_u8"].astype(np.float32).transpose(2, 0, 1) / 255.0) - 0.5) / 0.5)[None]
+    sk = torch.from_numpy((g["sketch_u8"].astype(np.float32)[None, None] / 255.0 > 0).astype(np.float32))
+    return img, sk
+
+
+def test_c1_bundled_face_sample(golden_dir):
+    """BASELINE config 1 (test_celeb.sh): the reference's bundled 256x256 face + sketch, batch 1 -- a realistic,
+    0.34 % dense sketch instead of synthetic noise.  Fixture = the reference's own outputs on it."""
+    g = _load(golden_dir, "c1_face.npz")
+    WM, WG = _weights(float(g["meta"][0]))
+    img, sk = _face_inputs(g)
+    assert 0.001 < float(sk.mean()) < 0.01
+    out = O.inference(WM, WG, img, sk)
+    assert np.array_equal(np.packbits(out["hard_mask"].numpy().astype(np.uint8)), g["hard_mask_bits"])
+    for k in ("composed", "mask", "coarse", "fine"):
+        assert _maxdiff(out[k][:, :, 96:160, 96:160], g[k + "_crop"]) < 5e-6, k
+        np.testing.assert_allclose(_summary(out[k]), g[k + "_sum"], rtol=2e-5, atol=2e-4)
+    # test.py:25-27 quantisation (no clamp, truncation): fp32 noise may move a value across an integer boundary
+    got = ((out["composed"] + 1) / 2 * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)
+    d = np.abs(got.astype(int) - g["composed_u8"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
 OPS = [("c3_s1_d1_elu", 8, 16, 3, 1, 1, "elu", 12, 16), ("c3_s2_d1_elu", 8, 16, 3, 2, 1, "elu", 12, 16),
        ("c3_s1_d2_elu", 8, 16, 3, 1, 2, "elu", 12, 16), ("c3_s1_d16_elu", 8, 16, 3, 1, 16, "elu", 20, 24),
        ("c3_s1_d1_relu", 8, 16, 3, 1, 1, "relu", 12, 16), ("c3_s1_d1_none", 12, 1, 3, 1, 1, None, 12, 16),
