@@ -184,6 +184,8 @@ bool wino48_eligible_layer(const LayerDef& d);
 int pack_wino48(se_ctx* c, Layer& L);
 bool winoup_eligible_layer(const LayerDef& d);
 int pack_winoup(se_ctx* c, Layer& L);
+bool winoup48_eligible_layer(const LayerDef& d);
+int pack_winoup48(se_ctx* c, Layer& L);
 
 int xcd_remap_enabled() {      // SE_XCD_REMAP=0 switches the XCD-aware tile order off (A/B measurements)
   static const int v = getenv("SE_XCD_REMAP") ? atoi(getenv("SE_XCD_REMAP")) : 1;
@@ -268,6 +270,7 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
   if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
+  if (winoup48_eligible_layer(d) && Cp == d.cin) return pack_winoup48(c, L);
   return 0;
 }
 
@@ -512,6 +515,57 @@ int pack_winoup(se_ctx* c, Layer& L) {
             const int ps = s_ ^ ((n >> 1) & 7);
             img[(((size_t)cls * 27 + it) * NP + n) * 32 + ps * 4 + e] = u;
           }
+      }
+    }
+  }
+  if (L.d_u) (void)hipFree(L.d_u);
+  if (L.d_ub) (void)hipFree(L.d_ub);
+  HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_ub, bias.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_ub, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// gen_deconv 48 -> 48 (se_wino_up48.hip): U = G g G^T per class as above; 14 iterations in the pairing of pack_wino48
+// (chunk c of pair pp holds in k-half h the 16-channel group ((2c+h) % 3) of position 2pp + ((2c+h) >= 3)); position 8
+// has no partner: the second k-half of iteration 13 stays zero.  48 rows in the MIXED order (8 features + their gates).
+bool winoup48_eligible_layer(const LayerDef& d) {
+  return d.k == 3 && d.stride == 1 && d.up && d.cin == 48 && d.cout == 48 && d.act != ACT_NONE;
+}
+int pack_winoup48(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const float Gm[3][2] = {{1.f, 0.f}, {1.f, 1.f}, {0.f, 1.f}};
+  const int NP = 48, NIT = 14;
+  std::vector<float> img((size_t)4 * NIT * NP * 32, 0.f), bias(NP, 0.f);
+  auto lo = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2); };
+  auto hi = [](int par, int a) { return par == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2); };
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    for (int n = 0; n < NP; ++n) {
+      const int t = n / 16, r = n % 16;
+      const int oc = r < 8 ? t * 8 + r : 24 + t * 8 + (r - 8);
+      bias[n] = L.b[oc];
+      for (int ic = 0; ic < 48; ++ic) {
+        float g[2][2];
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b) {
+            float v = 0.f;
+            for (int ky = lo(py, a); ky <= hi(py, a); ++ky)
+              for (int kx = lo(px, b); kx <= hi(px, b); ++kx) v += L.w[(((size_t)oc * d.cin + ic) * 3 + ky) * 3 + kx];
+            g[a][b] = v;
+          }
+        for (int pos = 0; pos < 9; ++pos) {
+          const int xi = pos / 3, nu = pos % 3;
+          float u = 0.f;
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) u += Gm[xi][a] * Gm[nu][b] * g[a][b];
+          const int pp = pos >> 1, u6 = (pos & 1) * 3 + ic / 16;        // index of the 16-channel group in the pair
+          const int it = pp * 3 + u6 / 2, kin = (u6 % 2) * 16 + ic % 16;
+          const int s_ = kin / 4, e = kin % 4;
+          const int ps = s_ ^ ((n >> 1) & 7);
+          img[(((size_t)cls * NIT + it) * NP + n) * 32 + ps * 4 + e] = u;
+        }
       }
     }
   }
@@ -802,6 +856,25 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * 96 + (double)B * Ho * Wo * 48), d.name,
                     alg * 9.0 / 36.0);                       // F(2x2,2x2) on the sub-pixel classes: 9 of 36 products
     HIPCHK(c, launch_winoup(wp, c->st));
+    return 0;
+  }
+  // gen_deconv 48 -> 48: F(2x2,2x2) on the sub-pixel classes with the K pairing of the 48-channel kernels (se_wino_up48.hip)
+  static const bool use_winoup48 = !(getenv("SE_WINOGRAD_UP48") && atoi(getenv("SE_WINOGRAD_UP48")) == 0);
+  if (use_wino && use_winoup && use_winoup48 && d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && d.cout == 48 &&
+      (long long)B * Hin * Win * 192 < (1ll << 31) && (long long)B * Ho * Wo * 96 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0) {
+    WinoParams wp;
+    memset(&wp, 0, sizeof wp);
+    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
+    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = 1; wp.th = Hin / 2; wp.tw = Win / 2;
+    wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+    wp.xcd = xcd_remap_enabled();
+    udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
+    udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
+    udiv_magic_host(1u, &wp.div_d_m, &wp.div_d_l);
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * 48 + (double)B * Ho * Wo * 24), d.name,
+                    alg * 9.0 / 36.0 * 28.0 / 27.0);         // 9 of 36 products, 28 k-halves executed for 27 of work
+    HIPCHK(c, launch_winoup48(wp, c->st));
     return 0;
   }
   {

@@ -113,6 +113,9 @@ hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
 // gen_deconv 96 -> 96 (48 gated), F(2x2,2x2) on the 4 sub-pixel classes (se_wino_up.hip): src NHWC 96 at (h, w), dst NHWC
 // 48 at (2h, 2w), upk [4 classes][27 iterations][96 MIXED rows][32], bias [96] MIXED order; h, w even; th = h/2, tw = w/2
 hipError_t launch_winoup(const WinoParams& p, hipStream_t st);
+// gen_deconv 48 -> 48 (24 gated) in the same form (se_wino_up48.hip): src NHWC 48 at (h, w), dst NHWC 24 at (2h, 2w), upk
+// [4 classes][14 iterations][48 MIXED rows][32] in the K pairing of the 48-channel kernels, bias [48] MIXED order
+hipError_t launch_winoup48(const WinoParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // bf16 raw-tile form of the 3x3 stride-1 gated conv 96 -> 192 (se_rconv16.hip)

@@ -141,20 +141,22 @@ def test_op_winograd48_path_vs_oracle(eng, case):
 WINOUP = [(8, 8, "elu"), (16, 24, "elu"), (64, 64, "elu"), (10, 14, "relu"), (34, 30, "elu"), (2, 2, "elu")]
 
 
+@pytest.mark.parametrize("cin", [96, 48])
 @pytest.mark.parametrize("case", WINOUP, ids=["%dx%d-%s" % c for c in WINOUP])
-def test_op_winograd_upsample_path_vs_oracle(eng, case):
-    """gen_deconv 96 -> 96 (nearest x2 + 3x3): F(2x2,2x2) Winograd on the four sub-pixel classes (se_wino_up.hip);
-    even source sizes take it, ragged tile counts and the image borders (zero padding on the upsampled grid) included."""
+def test_op_winograd_upsample_path_vs_oracle(eng, case, cin):
+    """gen_deconv 96 -> 96 and 48 -> 48 (nearest x2 + 3x3): F(2x2,2x2) Winograd on the four sub-pixel classes
+    (se_wino_up.hip / se_wino_up48.hip, the latter with two positions per three 32-k chunks); even source sizes take it,
+    ragged tile counts and the image borders (zero padding on the upsampled grid) included."""
     from oracle import sketchedit_oracle as O
     H, W, act = case
-    a = 1.5 / np.sqrt(96 * 9)
-    w = synth.uniform(19, "winoup.w%s" % (case,), (96, 96, 3, 3), -a, a)
-    b = synth.uniform(19, "winoup.b%s" % (case,), (96,), -0.3, 0.3)
-    x = synth.uniform(19, "winoup.x%s" % (case,), (3, 96, H, W), -1, 1)
+    a = 1.5 / np.sqrt(cin * 9)
+    w = synth.uniform(19, "winoup%d.w%s" % (cin, case), (cin, cin, 3, 3), -a, a)
+    b = synth.uniform(19, "winoup%d.b%s" % (cin, case), (cin,), -0.3, 0.3)
+    x = synth.uniform(19, "winoup%d.x%s" % (cin, case), (3, cin, H, W), -1, 1)
     y = eng.gated_conv2d(_cuda(x), w, b, upsample=True, act=act)
     xu = torch.from_numpy(x).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)      # utils.py:47
     ref = O.gated_conv(xu, torch.from_numpy(w), torch.from_numpy(b), 1, 1, act)
-    assert tuple(y.shape) == (3, 48, 2 * H, 2 * W)
+    assert tuple(y.shape) == (3, cin // 2, 2 * H, 2 * W)
     assert _md(y, ref) < TOL_OP
 
 
