@@ -1,0 +1,54 @@
+"""bench.py as the driver runs it: the one-line JSON contract, and the N > 1 code path (one rank per process, barrier +
+max-over-ranks timing, the packed output all-gather on a side stream) with what a 1-GPU box offers -- two ranks that
+share cuda:0 and exchange over gloo (RCCL refuses two ranks on one device; the nccl branch itself is covered by
+`bench.py --force-dist`, profiles/r02_c2_rccl_world1.json)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "1", "--batch", "2", "--size", "64", "--no-cpu-baseline", "--no-traffic"]
+
+
+def _one_json_line(out):
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must hold exactly one line, got %d:\n%s" % (len(lines), out[-2000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_prints_one_contract_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, cwd=ROOT, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert d["metric"] == "images/sec" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and 0.0 < roof["frac"] <= 1.0 and roof["peak"] == 157.3
+    assert d["parity"]["max_abs_composed"] < 1e-3 or d["parity"].get("max_abs_composed_same_hard_mask", 1.0) < 1e-3
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0",
+           "--check-gather", "--no-parity"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["per_gpu_batch"] == 2
+    assert d["config"]["collective"] and "all_gather" in d["config"]["collective"]
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job images per second
