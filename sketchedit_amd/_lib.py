@@ -63,6 +63,9 @@ def load_library():
             raise SketchEditHipError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU or PyTorch fallback for this path)" % LIB_PATH)
+        # PyTorch first: it brings its own HIP runtime (torch/lib/libamdhip64.so) and our library must bind to that one.
+        # Loaded the other way round the process ends up with two HIP runtimes and hipGetDeviceCount() returns 0.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         c_f = ctypes.c_void_p  # device/host float pointers are passed as raw addresses
         vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
