@@ -1,0 +1,19 @@
+"""Randomised sizes end to end (tools/fuzz_sizes.py): batch 1-3, heights / widths 16-152 in steps of 8, fp32 and bf16,
+default and low-latency execution, every case against the oracle (fp32: 1e-3, bf16: 3e-2 vs the oracle's bf16 mode)."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(900)
+def test_random_sizes_vs_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_fuzz_sizes", os.path.join(root, "tools", "fuzz_sizes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(60, 2024, verbose=False)
+    assert bad == 0
+    assert worst["f32"] < 1e-4 and worst["bf16"] < 3e-2
