@@ -17,3 +17,16 @@ def test_random_sizes_vs_oracle():
     bad, worst = mod.run(60, 2024, verbose=False)
     assert bad == 0
     assert worst["f32"] < 1e-4 and worst["bf16"] < 3e-2
+
+
+@pytest.mark.timeout(900)
+def test_random_layer_shapes_vs_oracle():
+    """tools/fuzz_ops.py: every gated-conv shape of the networks at random sizes (ragged tiles, odd grids), dilations,
+    both precisions, both launch shapes."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_fuzz_ops", os.path.join(root, "tools", "fuzz_ops.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(120, 77, verbose=False)
+    assert bad == 0
+    assert worst["f32"] < 1e-4
