@@ -39,12 +39,19 @@ def run(n, seed, verbose=True):
         prec = "bf16" if k % 3 == 2 else "f32"
         ll = bool(rng.randint(0, 2))
         img, sk = synth.make_inputs(B, H, W, seed=100 + k)
-        ref = O.inference(WM, WG, img, sk, act_dtype=torch.bfloat16 if prec == "bf16" else None)
+        # one case in four: a random combination of the option flags (editline_g.py:15-23) instead of test_celeb.sh's
+        fl = dict(use_cam=True, pool_type="max", no_mask_cc=False, no_mask_coarse=False, joint_train_inp=True)
+        if k % 4 == 3:
+            fl = dict(use_cam=bool(rng.randint(0, 2)), pool_type=("max", "avg")[int(rng.randint(0, 2))], no_mask_cc=bool(rng.randint(0, 2)),
+                      no_mask_coarse=bool(rng.randint(0, 2)), joint_train_inp=bool(rng.randint(0, 2)))
+        bits = (1 if fl["use_cam"] else 0) | (2 if fl["pool_type"] == "max" else 0) | (4 if fl["no_mask_cc"] else 0) | \
+            (8 if fl["no_mask_coarse"] else 0) | (16 if fl["joint_train_inp"] else 0)
+        ref = O.inference(WM, WG, img, sk, act_dtype=torch.bfloat16 if prec == "bf16" else None, **fl)
         e = engs[prec]
         ci, cs = torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda()
-        r = e.inference(ci, cs, FLAGS, visualize=True, low_latency=ll)
+        r = e.inference(ci, cs, bits, visualize=True, low_latency=ll)
         hard = ref["hard_mask"].cuda()
-        coarse, fine = e.netG(ci, ci, hard, hard, cs, FLAGS)
+        coarse, fine = e.netG(ci, ci, hard, hard, cs, bits)
         dm = float((r["mask"].cpu() - ref["mask"]).abs().max())
         dc = float((coarse.cpu() - ref["coarse"]).abs().max())
         df = float((fine.cpu() - ref["fine"]).abs().max())
@@ -53,7 +60,7 @@ def run(n, seed, verbose=True):
         worst[prec] = max(worst[prec], dm, dc, df)
         bad += 0 if ok else 1
         if verbose or not ok:
-            print("%2d %-4s B=%d %3dx%-3d ll=%d  mask %.2e coarse %.2e fine %.2e %s" % (k, prec, B, H, W, ll, dm, dc, df, "ok" if ok else "FAIL"), flush=True)
+            print("%2d %-4s B=%d %3dx%-3d ll=%d fl=%-2d mask %.2e coarse %.2e fine %.2e %s" % (k, prec, B, H, W, ll, bits, dm, dc, df, "ok" if ok else "FAIL"), flush=True)
     for e in engs.values():
         e.close()
     print("cases %d  failures %d  worst f32 %.2e  worst bf16 %.2e  (%.0f s)" % (n, bad, worst["f32"], worst["bf16"], time.time() - t0))
