@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started WITHOUT a launcher (no WORLD_SIZE in the environment), `python bench.py --gpus N`
+starts its own N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), relays
+rank 0's ONE JSON line and exits with the first failing rank's code.
+
 One "step" = one pass of EditLine2Model.forward(mode='inference') (netM -> threshold -> netG ->
 composite) over one synthetic batch per GPU: BASELINE.json config 2, 256x256, batch 32, fp32, inputs
 resident in HBM.  With N > 1 every rank runs its own batch shard (weak scaling, B per GPU fixed) and the packed
@@ -74,7 +78,8 @@ def cpu_baseline(budget_s=25.0):
     for size, B in ((256, 8), (256, 1), (512, 1)):
         img, sk = synth.make_inputs(B, size, size, seed=1234)
         img, sk = torch.from_numpy(img), torch.from_numpy(sk)
-        O.inference(WM, WG, img, sk)                      # warm-up (oneDNN primitive creation)
+        for _ in range(2):                                # two warm-ups: oneDNN primitive creation, allocator
+            O.inference(WM, WG, img, sk)
         times = []
         t_start = time.perf_counter()
         while len(times) < 2 or (time.perf_counter() - t_start < budget_s / 3 and len(times) < 5):
@@ -84,8 +89,8 @@ def cpu_baseline(budget_s=25.0):
         samples.append({"size": size, "batch": B, "images_per_sec": B / float(np.median(times)), "runs": len(times)})
     return {"value": samples[0]["images_per_sec"], "unit": "images/sec", "cores": cores, "host_cores": host,
             "thread_cap": 32, "kind": "port",
-            "sample": "oracle (torch CPU restatement of the reference): value = 256x256 batch 8, median of %d runs after 1 "
-                      "warm-up; `samples` also holds 256x256 batch 1 and 512x512 batch 1 (%.0f s of CPU work in all)"
+            "sample": "oracle (torch CPU restatement of the reference): value = 256x256 batch 8, median of %d runs after 2 "
+                      "warm-ups; `samples` also holds 256x256 batch 1 and 512x512 batch 1 (%.0f s of CPU work in all)"
                       % (samples[0]["runs"], time.perf_counter() - t_all),
             "samples": samples}
 
@@ -130,6 +135,46 @@ def pmc_traffic(argv_child, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher of N rank processes running this
+    very command line (one per GPU, the environment torch.distributed.run would give them) and relays rank 0's stdout.
+    A rank that fails takes the others down (their group) so that a dead peer cannot leave the rest in a collective."""
+    import signal
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    rc = 0
+    live = list(procs)
+    try:
+        while live and rc == 0:
+            time.sleep(0.05)
+            for p in list(live):
+                c = p.poll()
+                if c is not None:
+                    live.remove(p)
+                    rc = rc or c
+    finally:
+        for p in live:                       # only reached with survivors when a rank failed or on KeyboardInterrupt
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except OSError:
+                pass
+        for p in live:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+    return rc if rc >= 0 else 1
+
+
 def main():
     faulthandler.enable()
     # The contract is ONE line on stdout.  RCCL prints a version banner through C stdio (it shows up after the JSON line
@@ -156,14 +201,17 @@ def main():
     ap.add_argument("--check-gather", action="store_true", help="rank 0 verifies the gathered outputs (test aid)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather on the compute stream instead of a side stream")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gather even with one rank")
+    ap.add_argument("--nccl-channels", type=int, default=0, help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS); 0 = RCCL's own choice")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.dup2(real_stdout, 1)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; the line reports n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
     dist = None
     # --device / --backend exist only to exercise the N > 1 code path on a 1-GPU box (both ranks on cuda:0 over
     # gloo); the driver's runs use the defaults: one rank per GPU (LOCAL_RANK) over nccl = RCCL.
@@ -175,9 +223,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
         if args.backend == "nccl":
-            # The exchange is small (33.5 MB per rank and step at 256x256 batch 32) and runs under the next forward: a few RCCL
-            # channels carry it easily, and every channel is a workgroup that occupies a CU the convolutions want.
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+            # The exchange is small (33.5 MB per rank and step at 256x256 batch 32) and runs under the next forward; every
+            # RCCL channel is a workgroup on a CU the convolutions want, so a cap MAY pay -- unmeasured (no multi-GPU box
+            # in the build loop), hence opt-in: RCCL's own channel choice is the default.
+            if args.nccl_channels > 0:
+                os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_channels)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -213,7 +263,7 @@ def main():
 
     def forward(o):
         if args.graph:
-            r = eng.inference(img, sk, FLAGS, low_latency=low_latency, graph=True)
+            r = state["graph_out"] = eng.inference(img, sk, FLAGS, low_latency=low_latency, graph=True)
             if use_dist:
                 o[:, 0:3].copy_(r["composed"])
                 o[:, 3:4].copy_(r["mask"])
@@ -257,6 +307,10 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    timed_image0 = None                                   # image 0 of the LAST timed step (parity leg)
+    if rank == 0:
+        g = state.get("graph_out")
+        timed_image0 = torch.cat([g["composed"][0:1], g["mask"][0:1]], 1) if g else outs[state["last"]][0:1].clone()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -335,12 +389,13 @@ def main():
         WG = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()}
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         ref = O.inference(WM, WG, img_h[:1], sk_h[:1])
-        ll = eng.is_low_latency(B, S, S, low_latency)       # the execution mode of the timed run
-        r1 = eng.inference(img[:1].contiguous(), sk[:1].contiguous(), FLAGS, visualize=True, low_latency=ll)
+        # what is compared is image 0 of the packed (B,4,H,W) output the LAST TIMED step wrote (planes 0-2 composite, plane
+        # 3 soft mask); the hard mask netG saw is the threshold of that very fp32 plane (editline2_model.py:347)
+        r1 = {"composed": timed_image0[:, 0:3], "mask": timed_image0[:, 3:4], "hard": (timed_image0[:, 3:4] > 0.5).float()}
         flips = int((r1["hard"].cpu() != ref["hard_mask"]).sum())
         parity = {"max_abs_composed": float((r1["composed"].cpu() - ref["composed"]).abs().max()),
                   "max_abs_mask": float((r1["mask"].cpu() - ref["mask"]).abs().max()),
-                  "hard_mask_flips": flips, "image": 0, "tolerance": 1e-3 if args.dtype == "f32" else None,
+                  "hard_mask_flips": flips, "image": 0, "of": "the last timed step's own output (batch %d)" % B, "tolerance": 1e-3 if args.dtype == "f32" else None,
                   "comparator": "fp32 oracle"}
         if flips and args.dtype == "f32":
             # a soft-mask value within float noise of 0.5 thresholded differently (editline2_model.py:347): netG then saw a

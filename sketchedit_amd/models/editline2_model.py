@@ -79,7 +79,11 @@ class EditLine2Model(torch.nn.Module):
         with torch.no_grad():
             return eng.inference_u8(inputs.float().contiguous(), line.float().contiguous(), _lib.flags_from_opt(self.opt))
 
-    def forward(self, data, mode):
+    def forward(self, data, mode, low_latency=None):
+        """`low_latency` (no reference counterpart): None = the Engine picks the execution mode from the call's size,
+        True / False = pinned.  Results are bit-identical across batch compositions only WITHIN one mode
+        (include/sketchedit_hip.h), so callers whose batch size varies per request (serve.BatchingServer,
+        shard.sharded_inference) pin it."""
         inputs, real_image, line, line_full, _ = self.preprocess_input(data)
         if mode not in ("inference", "visualize"):
             raise ValueError("|mode| is invalid")
@@ -89,7 +93,7 @@ class EditLine2Model(torch.nn.Module):
         flags = _lib.flags_from_opt(self.opt)
         with torch.no_grad():
             r = eng.inference(inputs.float().contiguous(), line.float().contiguous(), flags,
-                              visualize=(mode == "visualize"))
+                              visualize=(mode == "visualize"), low_latency=low_latency)
         if mode == "inference":
             return r["composed"], r["mask"]
         return {"mask": r["hard"], "maskim": r["maskim"], "coarse": r["coarse"], "fine": r["fine"],

@@ -37,12 +37,24 @@ def _to_image(generated, size_raw):
     return Image.fromarray(g[0].transpose((1, 2, 0))).resize(size_raw)
 
 
-def process_image(model, img, mask):
-    """One request, as demo.py:39-73 handles it: PIL image + PIL sketch/mask in, PIL result out."""
+def _accepts_low_latency(model):
+    import inspect
+    try:
+        return "low_latency" in inspect.signature(getattr(model, "forward", model)).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def process_image(model, img, mask, low_latency=None):
+    """One request, as demo.py:39-73 handles it: PIL image + PIL sketch/mask in, PIL result out.  `low_latency` pins the
+    library's execution mode (EditLine2Model.forward); None = by call size."""
     import torch
     x, m, size_raw = _to_tensors(img, mask)
     with torch.no_grad():
-        generated, _ = model({"image": x, "mask": m}, mode="inference")
+        if low_latency is None:
+            generated, _ = model({"image": x, "mask": m}, mode="inference")
+        else:
+            generated, _ = model({"image": x, "mask": m}, mode="inference", low_latency=low_latency)
     return _to_image(generated, size_raw)
 
 
@@ -65,23 +77,35 @@ def create_models_for_gpus(opt, gpu_ids=None):
 class BatchingServer:
     """Concurrent `submit(img, mask)` calls are grouped by working size and run as one forward per group
     (up to `max_batch` requests, waiting at most `max_wait_s` for company).  The forward treats the images of a
-    batch independently, so a request's result does not depend on what it was batched with.
+    batch independently and an image's result is bit-identical across batch positions WITHIN one
+    execution mode of the library (include/sketchedit_hip.h: default vs SE_FLAG_LOW_LATENCY run different kernels that
+    agree to fp32 rounding -- enough to flip a soft-mask value sitting on the 0.5 threshold).  `mode_policy`:
+      "pinned" (default): the mode is a function of the request's working size and `max_batch` only -- low-latency iff
+          even a full group of this size (`max_batch` images) is a small call -- so a request's result does NOT depend
+          on what it was batched with;
+      "by_size": the Engine picks the mode from each group's actual size (lowest latency for a lone request; results
+          may differ at fp32 rounding level between a lone and a batched run of the same request).
 
     `models` = one model per GPU (create_models_for_gpus): every model gets its own worker thread, all workers pull
     groups from the one shared queue -- dynamic batching across the GPUs of the node; an idle GPU
     takes the next group, so the load balances itself.  `model` = the single-GPU form."""
 
-    def __init__(self, model=None, max_batch=32, max_wait_s=0.005, models=None):
+    def __init__(self, model=None, max_batch=32, max_wait_s=0.005, models=None, mode_policy="pinned"):
+        if mode_policy not in ("pinned", "by_size"):
+            raise ValueError(mode_policy)
+        self.mode_policy = mode_policy
         self.models = list(models) if models is not None else [model]
         if not self.models or any(m is None for m in self.models):
             raise ValueError("BatchingServer needs a model (or a list of models, one per GPU)")
         self.model = self.models[0]
+        self._has_knob = [_accepts_low_latency(m) for m in self.models]
         self.max_batch, self.max_wait_s = max_batch, max_wait_s
         self._lock = threading.Condition()
         self._queue = []          # (x, m, size_raw, slot)
         self._stop = False
         self.batches = []         # sizes of the batches that were run (observability / tests)
         self.batches_by_model = [0] * len(self.models)
+        self._collecting = False  # one worker at a time waits out a group's deadline; the others block on the condition
         self._workers = [threading.Thread(target=self._run, args=(k,), daemon=True) for k in range(len(self.models))]
         for t in self._workers:
             t.start()
@@ -107,27 +131,52 @@ class BatchingServer:
             t.join()
 
     def _take_group(self):
-        """Oldest request's size decides the group; wait briefly for more requests of that size."""
+        """Oldest request's size decides the group; wait briefly for more requests of that size.  Only ONE worker at a
+        time is the collector (the others sleep on the condition until it has taken its group), and the collector
+        re-reads the head of the queue after every wake-up, so no worker waits out a deadline for a stale shape while
+        requests of another shape are queued and its GPU is idle."""
         with self._lock:
-            while not self._queue and not self._stop:
-                self._lock.wait()
-            if not self._queue:
-                return None
-            shape = tuple(self._queue[0][0].shape)
-            deadline = time.monotonic() + self.max_wait_s
-            while self._queue and sum(1 for q in self._queue if tuple(q[0].shape) == shape) < self.max_batch:
-                left = deadline - time.monotonic()
-                if left <= 0 or self._stop:
-                    break
-                self._lock.wait(left)
-            group = [q for q in self._queue if tuple(q[0].shape) == shape][:self.max_batch]
-            taken = {id(q) for q in group}       # (list.remove would compare the tensors inside the tuples)
-            self._queue = [q for q in self._queue if id(q) not in taken]
-            return group
+            while True:
+                while (not self._queue or self._collecting) and not self._stop:
+                    self._lock.wait()
+                if not self._queue:
+                    return None                       # stopped and drained
+                if self._collecting:                  # stopping: let the collector finish its group first
+                    self._lock.wait(0.001)
+                    continue
+                self._collecting = True
+                try:
+                    shape = tuple(self._queue[0][0].shape)
+                    deadline = time.monotonic() + self.max_wait_s
+                    while True:
+                        n = sum(1 for q in self._queue if tuple(q[0].shape) == shape)
+                        left = deadline - time.monotonic()
+                        if n >= self.max_batch or left <= 0 or self._stop:
+                            break
+                        self._lock.wait(left)
+                    group = [q for q in self._queue if tuple(q[0].shape) == shape][:self.max_batch]
+                    taken = {id(q) for q in group}    # (list.remove would compare the tensors inside the tuples)
+                    self._queue = [q for q in self._queue if id(q) not in taken]
+                finally:
+                    self._collecting = False
+                    self._lock.notify_all()           # the next collector may start on what is left
+                return group
+
+    def _mode(self, shape):
+        """Execution mode of a group of requests of working size `shape` (1,3,H,W) -- see the class docstring."""
+        if self.mode_policy == "by_size":
+            return None
+        from ._lib import Engine
+        return Engine.is_low_latency(self.max_batch, shape[2], shape[3])
+
+    def _forward(self, k, x, m):
+        model = self.models[k]
+        if self._has_knob[k]:
+            return model({"image": x, "mask": m}, mode="inference", low_latency=self._mode(tuple(x.shape)))
+        return model({"image": x, "mask": m}, mode="inference")   # a model object without the execution-mode knob
 
     def _run(self, k):
         import torch
-        model = self.models[k]
         while True:
             group = self._take_group()
             if group is None:
@@ -138,7 +187,7 @@ class BatchingServer:
                 x = torch.cat([q[0] for q in group], 0)
                 m = torch.cat([q[1] for q in group], 0)
                 with torch.no_grad():
-                    generated, _ = model({"image": x, "mask": m}, mode="inference")
+                    generated, _ = self._forward(k, x, m)
                 with self._lock:
                     self.batches.append(len(group))
                     self.batches_by_model[k] += 1

@@ -30,17 +30,36 @@ def gather_batch(local, group=None):
     return out
 
 
+def global_mode(n, H, W):
+    """The library's execution mode for a GLOBAL batch of n images: every rank runs its shard in the mode the unsharded
+    call would run in, so an image's result does not depend on the world size (the library guarantees bit-identical
+    results across batch positions and ranks only within one mode, include/sketchedit_hip.h)."""
+    from ._lib import LOW_LATENCY_MAX_PIXELS
+    return n * H * W <= LOW_LATENCY_MAX_PIXELS
+
+
+def _accepts(forward, name):
+    import inspect
+    try:
+        return name in inspect.signature(forward).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 def sharded_inference(forward, image, sketch, group=None):
-    """Run `forward(image_shard, sketch_shard)` on this rank's rows of the global batch and return the gathered global
-    (composed, mask).  `forward` returns either the packed (b,4,H,W) tensor (Engine.inference_packed) or a
-    (composed, mask) pair, which is packed here; one collective either way.  Requires batch % world == 0."""
+    """Run `forward(image_shard, sketch_shard[, low_latency=...])` on this rank's rows of the global batch and return
+    the gathered global (composed, mask).  `forward` returns either the packed (b,4,H,W) tensor
+    (Engine.inference_packed) or a (composed, mask) pair, which is packed here; one collective either way.  When
+    `forward` has a `low_latency` parameter it receives the mode of the GLOBAL batch (`global_mode`), not the one its
+    shard's size would select.  Requires batch % world == 0."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = image.shape[0]
     if n % world:
         raise ValueError("global batch %d is not a multiple of the world size %d" % (n, world))
     lo, hi = shard_range(n, world, rank)
-    out = forward(image[lo:hi].contiguous(), sketch[lo:hi].contiguous())
+    kw = {"low_latency": global_mode(n, image.shape[2], image.shape[3])} if _accepts(forward, "low_latency") else {}
+    out = forward(image[lo:hi].contiguous(), sketch[lo:hi].contiguous(), **kw)
     packed = out if isinstance(out, torch.Tensor) else torch.cat([out[0], out[1]], 1)
     full = gather_batch(packed, group)
     c = full.shape[1] - 1

@@ -39,6 +39,22 @@ def test_bench_prints_one_contract_line():
 
 @pytest.mark.timeout(900)
 def test_bench_two_ranks_share_the_gpu_over_gloo():
+    # plain `python bench.py --gpus 2`: no external launcher, bench.py starts its own ranks (the form the driver's N=1
+    # command takes at N=2/4/8)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0",
+           "--check-gather", "--no-parity"] + SMALL
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["per_gpu_batch"] == 2
+    assert d["config"]["collective"] and "all_gather" in d["config"]["collective"]
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job images per second
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The launcher form of the contract: torch.distributed.run starts the ranks, bench.py reads RANK / WORLD_SIZE."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -49,6 +65,14 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json_line(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["per_gpu_batch"] == 2
-    assert d["config"]["collective"] and "all_gather" in d["config"]["collective"]
-    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job images per second
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_propagates_a_rank_failure():
+    """A rank that dies must end the whole job with a non-zero code and no JSON line (here: an impossible device index)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "63",
+           "--no-parity"] + SMALL
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode != 0 and not r.stdout.strip()

@@ -274,6 +274,49 @@ def test_batching_server_dispatches_over_several_models():
     assert all(f.calls > 0 for f in fakes), [f.calls for f in fakes]
 
 
+def test_execution_mode_is_pinned_where_batch_composition_varies():
+    """the library's results are bit-identical across batch positions only within one execution mode,
+    so the callers whose batch size varies pin the mode: BatchingServer from (max_batch, working size) -- never from the
+    group's actual size -- and sharded_inference from the GLOBAL batch, not from the shard."""
+    import torch
+    from PIL import Image
+    from sketchedit_amd import serve, shard
+
+    class Rec:
+        def __init__(self):
+            self.modes = []
+
+        def forward(self, data, mode, low_latency=None):
+            self.modes.append((data["image"].shape[0], low_latency))
+            return data["image"], data["mask"]
+        __call__ = forward
+
+    img, sk = Image.new("RGB", (256, 256)), Image.new("L", (256, 256))
+    for max_batch, want in ((2, True), (32, False)):            # 2 x 256x256 is a small call, 32 x 256x256 is not
+        m = Rec()
+        srv = serve.BatchingServer(m, max_batch=max_batch, max_wait_s=0.0)
+        srv.submit(img, sk)                                      # a lone request: group of 1 whatever max_batch is
+        srv.close()
+        assert m.modes == [(1, want)], m.modes
+    m = Rec()
+    srv = serve.BatchingServer(m, max_batch=32, max_wait_s=0.0, mode_policy="by_size")
+    srv.submit(img, sk)
+    srv.close()
+    assert m.modes == [(1, None)]
+    with pytest.raises(ValueError):
+        serve.BatchingServer(m, mode_policy="fastest")
+    # shard: the forward sees the mode of the global batch (8 x 256x256 -> default), not of its shard
+    seen = []
+
+    def fwd(i, s, low_latency=None):
+        seen.append(low_latency)
+        return torch.cat([i, s], 1)
+    shard.sharded_inference(fwd, torch.zeros(8, 3, 256, 256), torch.zeros(8, 1, 256, 256))
+    shard.sharded_inference(fwd, torch.zeros(4, 3, 256, 256), torch.zeros(4, 1, 256, 256))
+    assert seen == [False, True]
+    assert shard.global_mode(8, 256, 256) is False and shard.global_mode(1, 512, 512) is True
+
+
 def test_check_checkpoint_missing_key_not_hidden_by_suffix_match(tmp_path):
     """A problem line that merely ENDS with a key name must not hide that the key itself is missing."""
     import importlib.util
