@@ -9,8 +9,13 @@ Tolerances.  The north star's 1e-3 bound is an fp32 statement; bf16 keeps 8 sign
   * a whole network: the roundings after every layer turn fp32-level differences into occasional one-spacing flips that
     propagate.  Two equally valid placements of the same roundings (fp64 vs fp32 accumulation, pre-summed sub-pixel
     weights vs the 3x3 on the upsampled grid) differ by 6e-3 .. 1.1e-2 on the soft mask and 3e-3 .. 6e-3 on the outputs at
-    64x64 .. 128x128 (measured on the CPU).  Bound used here: 3e-2 max-abs, 3e-3 mean-abs; a handful of soft-mask
-    pixels near 0.5 may threshold differently (<= 0.5 % of the pixels), so netG is compared on the oracle's hard mask.
+    64x64 .. 128x128 (measured on the CPU).  Bound used here: 3e-2 max-abs, 3e-3 mean-abs at every size (no slack for
+    large images); a handful of soft-mask pixels near 0.5 may threshold differently (<= 0.5 % of the pixels), so netG is
+    compared on the oracle's hard mask.
+  * what makes that bound a MEASURED one (test_bf16_error_triangle): on the same inputs and the same hard mask the HIP
+    bf16 result must be no farther from the fp32 oracle than the bf16 oracle itself is -- max-abs and mean-abs of
+    |HIP_bf16 - fp32 oracle| <= TRIANGLE x those of |bf16 oracle - fp32 oracle| -- i.e. the GPU path loses no more
+    accuracy to bf16 than the reference-pinned CPU definition of the bf16 computation does.
 """
 import os
 
@@ -24,6 +29,7 @@ pytestmark = pytest.mark.gpu
 
 BF = torch.bfloat16
 TOL_NET, TOL_NET_MEAN = 3e-2, 3e-3
+TRIANGLE = 1.25
 FLAGS = 1 | 2 | 16
 
 
@@ -199,7 +205,7 @@ def test_inference_bf16_vs_oracle_bf16(eng, case):
     coarse, fine = eng.netG(ci, ci, hard, hard, cs, FLAGS)
     for got, want in ((coarse, ref["coarse"]), (fine, ref["fine"])):
         d = np.abs(_np(got) - _np(want))
-        assert d.max() < TOL_NET * (2 if H >= 256 else 1) and d.mean() < TOL_NET_MEAN
+        assert d.max() < TOL_NET and d.mean() < TOL_NET_MEAN
     # against the fp32 oracle the bf16 path is a bf16 computation: reported, loosely bounded
     d32 = np.abs(_np(fine) - _np(O.netG_forward(WG, img, img, ref["hard_mask"], ref["hard_mask"], sk)[1]))
     assert d32.mean() < 2e-2
@@ -221,3 +227,69 @@ def test_bf16_batch_shard_invariance_and_config5_size(eng):
     assert float((comp - r["composed"]).abs().max()) < 1e-6
     one = eng.inference(ci[2:3].contiguous(), cs[2:3].contiguous(), FLAGS, low_latency=False)
     assert torch.equal(one["composed"], r["composed"][2:3])
+
+
+@pytest.mark.parametrize("size", [64, 128, 256])
+def test_bf16_error_triangle(eng, size):
+    """|HIP_bf16 - fp32 oracle| <= 1.25 x |bf16 oracle - fp32 oracle| (max-abs and mean-abs), on the soft mask of netM and
+    on both outputs of netG, all three computations fed the SAME hard mask (the fp32 oracle's)."""
+    from oracle import sketchedit_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    B = 2 if size <= 64 else 1
+    img, sk = synth.make_inputs(B, size, size, seed=1234)
+    WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
+    ref32 = O.inference(WM, WG, img, sk)
+    hard = ref32["hard_mask"]
+    with torch.no_grad():
+        m16, _ = O.netM_forward(WM, torch.from_numpy(img), torch.from_numpy(sk), act_dtype=BF)
+        c16, f16 = O.netG_forward(WG, img, img, hard, hard, sk, act_dtype=BF)
+    ci, cs = _cuda(img), _cuda(sk)
+    gm, _ = eng.netM(ci, cs, want_image=False)
+    gc, gf = eng.netG(ci, ci, hard.cuda(), hard.cuda(), cs, FLAGS)
+    report = {}
+    for name, got, o16, o32 in (("mask", gm, m16, ref32["mask"]), ("coarse", gc, c16, ref32["coarse"]), ("fine", gf, f16, ref32["fine"])):
+        d_hip = np.abs(_np(got).astype(np.float64) - _np(o32))
+        d_or = np.abs(_np(o16).astype(np.float64) - _np(o32))
+        report[name] = (d_hip.max(), d_or.max(), d_hip.mean(), d_or.mean())
+    print("bf16 triangle %d: " % size + "  ".join("%s max %.2e/%.2e mean %.2e/%.2e" % ((k,) + v) for k, v in report.items()))
+    for name, (hmax, omax, hmean, omean) in report.items():
+        assert hmean <= TRIANGLE * omean, "%s: mean |HIP-fp32| %.3e > %.2f x mean |oracle_bf16-fp32| %.3e" % (name, hmean, TRIANGLE, omean)
+        assert hmax <= TRIANGLE * omax, "%s: max |HIP-fp32| %.3e > %.2f x max |oracle_bf16-fp32| %.3e" % (name, hmax, TRIANGLE, omax)
+
+
+@pytest.mark.timeout(1200)
+def test_config5_full_size(eng):
+    """BASELINE config 5 at ITS size -- 512x512, batch 16, bf16 -- in the suite (not only in bench.py): images 0 and 9 of
+    the batch against the oracle's bf16 mode (soft mask of the batch-16 run; netG's outputs from a batch-16 netG call in
+    which these two images get the oracle's hard mask, so that a threshold flip does not change their input), plus the
+    size-independent properties on all 16 images."""
+    from oracle import sketchedit_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    B, S, picks = 16, 512, (0, 9)
+    img, sk = synth.make_inputs(B, S, S, seed=1234)
+    WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
+    ci, cs = _cuda(img), _cuda(sk)
+    r = eng.inference(ci, cs, FLAGS, visualize=True, low_latency=False)
+    for k in ("composed", "mask", "fine", "coarse"):
+        assert torch.isfinite(r[k]).all(), k
+    assert float(r["mask"].min()) >= 0 and float(r["mask"].max()) <= 1
+    assert torch.equal(r["hard"], (r["mask"] > 0.5).float())
+    comp = r["fine"] * r["mask"] + ci * (1 - r["mask"])
+    assert float((comp - r["composed"]).abs().max()) < 1e-6
+    hard_mix = r["hard"].clone()
+    refs = {}
+    for k in picks:
+        refs[k] = O.inference(WM, WG, img[k:k + 1], sk[k:k + 1], act_dtype=BF)
+        d = np.abs(_np(r["mask"][k:k + 1]) - _np(refs[k]["mask"]))
+        assert d.max() < TOL_NET and d.mean() < TOL_NET_MEAN, (k, d.max(), d.mean())
+        flips = float((_np(r["hard"][k:k + 1]) != _np(refs[k]["hard_mask"])).mean())
+        assert flips < 5e-3, "image %d: hard-mask flips on %.4f of the pixels" % (k, flips)
+        hard_mix[k:k + 1] = refs[k]["hard_mask"].cuda()
+    coarse, fine = eng.netG(ci, ci, hard_mix, hard_mix, cs, FLAGS)
+    for k in picks:
+        for got, want in ((coarse[k:k + 1], refs[k]["coarse"]), (fine[k:k + 1], refs[k]["fine"])):
+            d = np.abs(_np(got) - _np(want))
+            assert d.max() < TOL_NET and d.mean() < TOL_NET_MEAN, (k, d.max(), d.mean())
+    # an image's result does not depend on its batch: image 9 alone, same mode
+    one = eng.inference(ci[9:10].contiguous(), cs[9:10].contiguous(), FLAGS, low_latency=False)
+    assert torch.equal(one["composed"], r["composed"][9:10]) and torch.equal(one["mask"], r["mask"][9:10])
