@@ -37,16 +37,29 @@ class SketchEditHipError(RuntimeError):
 
 
 def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> sketchedit_amd/lib/libsketchedit_hip.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "se_kernels.h"), os.path.join(CSRC, "se_device.h"), os.path.join(_HERE, "..", "include", "sketchedit_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    """hipcc --offload-arch=gfx950 -> sketchedit_amd/lib/libsketchedit_hip.so (cross-compiles without a GPU).
+    One object per source (compiled in parallel, rebuilt only when the source or a header is newer), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, "se_kernels.h"), os.path.join(CSRC, "se_device.h"), os.path.join(_HERE, "..", "include", "sketchedit_hip.h")]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+    objdir = os.path.join(_HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp, op = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
+            jobs.append(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
+        list(ex.map(run, jobs))
+    run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 

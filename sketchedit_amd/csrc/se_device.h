@@ -76,6 +76,9 @@ DEVFN float fast_exp(float x) { return __expf(x); }
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEVFN float elu_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
 DEVFN float sigmoid_fast(float x) { return fast_rcp(1.f + fast_exp(-x)); }
+// tanh(x) = 1 - 2 / (1 + e^(2x)): saturates correctly (e^(2x) -> inf gives 1, -> 0 gives -1); absolute error ~2e-7 -- ocml's
+// tanhf costs ~40 VALU instructions, a third of small_conv_kernel<3>'s multiply-add work
+DEVFN float tanh_fast(float x) { return 1.f - 2.f * fast_rcp(1.f + fast_exp(2.f * x)); }
 
 // ---- division by a launch-invariant divisor (Granlund-Montgomery, round-up form): exact for every 32-bit x.
 // Host (se_kernels.h udiv_magic_host): l = ceil(log2 d), m = floor(2^32 * (2^l - d) / d) + 1.  Device: 2 shifts, 1 mul_hi, 2 adds instead of the

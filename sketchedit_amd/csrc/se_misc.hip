@@ -70,107 +70,191 @@ ProfScope::~ProfScope() {
 // ------------------------------------------------------------------------------------------------
 // BF16: the 12-channel input is stored as bf16 NHWC with a 16-channel pixel stride (channels 12-15 are zero); the
 // stage-2 input written by mode 2 is then bf16 NHWC8.  Arithmetic and the NCHW outputs stay fp32.
+//
+// What bounds it (round 3; the round-2 form was one pixel per lane, 9 pixel loads and 108 scalar FMAs per output channel):
+// 324 FMAs per pixel are 69 us of VALU issue at 256x256 B=32 -- the kernel was VALU-bound, with the vector L1 (27 16-byte
+// loads per pixel) right behind, and its 3.4x HBM over-fetch came from vertically adjacent row blocks landing on
+// different XCDs (round-robin dispatch), so that no L2 ever saw a row twice.  Now:
+//   * a lane owns a COLUMN STRIP of SR = 4 output rows and walks the SR + 2 input rows once: 4.5 pixel loads per output
+//     instead of 9 (an input row feeds the <= 3 output rows that tap it while it is in registers);
+//   * the multiply-adds are packed (v_pk_fma_f32: channel pairs (2i, 2i+1) into a two-lane accumulator, summed once at
+//     the end) -- half the VALU issue slots;
+//   * blocks are handed to the XCDs in contiguous ranges (xcd_tile), so the two halo rows a strip shares with its
+//     vertical neighbours come out of the same L2.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int COUT, bool BF16>
 __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p) {
+  constexpr int SR = 4;                       // output rows per lane (a ragged last strip is masked)
   const int HW = p.H * p.W;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)p.B * HW) return;
-  const int b = idx / HW, rem = idx - (long)b * HW;
-  const int y = rem / p.W, x = rem - y * p.W;
-  float acc[COUT];
+  const int strips = (p.H + SR - 1) / SR;
+  const long sidx = (long)xcd_tile(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (image, strip, column)
+  if (sidx >= (long)p.B * strips * p.W) return;
+  const int b = (int)(sidx / ((long)strips * p.W));
+  const int rem0 = (int)(sidx - (long)b * strips * p.W);
+  const int sy = rem0 / p.W, x = rem0 - sy * p.W, y0 = sy * SR;
+  f32x2 acc[SR][COUT];
 #pragma unroll
-  for (int c = 0; c < COUT; ++c) acc[c] = p.b[c];
+  for (int o = 0; o < SR; ++o)
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = y + ky - 1;
+    for (int c = 0; c < COUT; ++c) acc[o][c] = (f32x2){p.b[c], 0.f};
+  const f32x2* w2 = (const f32x2*)p.w;        // [COUT][9 taps][6 channel pairs]
+  // zero padding through the buffer range check: a tap outside the image gets an out-of-range offset and the hardware
+  // returns zeros (one select per pixel load instead of twelve per pixel; no branch).  32-bit offsets from the first
+  // image of this launch (launch_small_conv splits batches whose activation exceeds 2 GB).
+  constexpr int PXB = BF16 ? 32 : 48;         // bytes per input pixel
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((unsigned)p.B * (unsigned)HW * (unsigned)PXB), 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  // raw dwords of one input row: 3 pixels x 12 channels (fp32: 3 x 16 B per pixel; bf16: 16 B + 8 B per pixel)
+  constexpr int RD = BF16 ? 6 : 12;
+  auto load_row = [&](int r, unsigned (&raw)[3][RD]) {
+    const int iy = y0 - 1 + r;
+    const bool rowin = (unsigned)iy < (unsigned)p.H;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = x + kx - 1;
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-        float v[12];
-        if (BF16) {
-          const uint4 a = *(const uint4*)((const char*)p.x + ((long)(b * p.H + iy) * p.W + ix) * 32);
-          const uint2 c = *(const uint2*)((const char*)p.x + ((long)(b * p.H + iy) * p.W + ix) * 32 + 16);
-          const unsigned u[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
+      const bool in = rowin && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = in ? (unsigned)((b * p.H + iy) * p.W + ix) * (unsigned)PXB : 0x80000000u;
+      if (BF16) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+        const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 16, 0);
+        raw[kx][0] = a[0]; raw[kx][1] = a[1]; raw[kx][2] = a[2]; raw[kx][3] = a[3]; raw[kx][4] = c[0]; raw[kx][5 % RD] = c[1];
+      } else {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) { v[2 * i] = bf16_lo(u[i]); v[2 * i + 1] = bf16_hi(u[i]); }
-        } else {
-          const f32x4* src = (const f32x4*)(p.x + ((long)(b * p.H + iy) * p.W + ix) * 12);
-          const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
-          const float vv[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+        for (int q = 0; q < 3; ++q) {
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, q * 16, 0);
 #pragma unroll
-          for (int i = 0; i < 12; ++i) v[i] = vv[i];
+          for (int e = 0; e < 4; ++e) raw[kx][(q * 4 + e) % RD] = t[e];
         }
+      }
+    }
+  };
+  auto use_row = [&](int r, const unsigned (&raw)[3][RD]) {      // input row y0 - 1 + r feeds output row o with ky = r - o
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f32x2 v[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        v[i] = BF16 ? (f32x2){bf16_lo(raw[kx][i % RD]), bf16_hi(raw[kx][i % RD])}
+                    : (f32x2){__uint_as_float(raw[kx][(2 * i) % RD]), __uint_as_float(raw[kx][(2 * i + 1) % RD])};
+#pragma unroll
+      for (int o = 0; o < SR; ++o) {
+        const int ky = r - o;
+        if (ky < 0 || ky > 2) continue;        // wave-uniform
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
-          const float* wc = p.w + (c * 9 + ky * 3 + kx) * 12;
+          const f32x2* wc = w2 + (c * 9 + ky * 3 + kx) * 6;
 #pragma unroll
-          for (int i = 0; i < 12; ++i) acc[c] = fmaf(v[i], wc[i], acc[c]);
+          for (int i = 0; i < 6; ++i) acc[o][c] = v[i] * wc[i] + acc[o][c];
         }
       }
     }
+  };
+  // two-deep software pipeline over the SR + 2 input rows: the loads of row r + 1 are in flight under the FMAs of row r.
+  // The row loop is NOT unrolled (two rows per trip, so the buffers stay compile-time): unrolled, hipcc hoists all 54
+  // loads and all 324 weight s_loads to the top and spills SGPRs into VGPR lanes (263 VGPRs, one wave per SIMD); rolled,
+  // ky = r - o is a wave-uniform run-time value and the weights of the (<= 3) output rows a row feeds are fetched
+  // through the scalar cache as they are needed.
+  unsigned rawA[3][RD], rawB[3][RD];
+  load_row(0, rawA);
+#pragma unroll 1
+  for (int r = 0; r < SR + 2; r += 2) {
+    load_row(r + 1, rawB);
+    use_row(r, rawA);
+    if (r + 2 < SR + 2) load_row(r + 2, rawA);
+    use_row(r + 1, rawB);
   }
-  if (p.mode == 4) {   // raw conv output (unit tests of the passthrough rule, utils.py:27)
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) p.out_nchw[((long)b * COUT + c) * HW + rem] = acc[c];
-    return;
-  }
-  if (p.mode == 0) {
-    const float m = sigmoidf_(acc[0]);
-    p.out_nchw[p.out_bs ? (long)b * p.out_bs + rem : idx] = m;
-    if (p.hard) p.hard[idx] = m > 0.5f ? 1.f : 0.f;
-    return;
-  }
-  if constexpr (COUT == 3) {
-    float t[3];
+  for (int o = 0; o < SR; ++o) {
+    const int y = y0 + o;
+    if (y >= p.H) break;
+    const int rem = y * p.W + x;
+    const long idx = (long)b * HW + rem;
+    float a1[COUT];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) t[c] = tanhf(acc[c]);
-    if (p.out_nchw) {
+    for (int c = 0; c < COUT; ++c) a1[c] = acc[o][c][0] + acc[o][c][1];
+    if (p.mode == 4) {   // raw conv output (unit tests of the passthrough rule, utils.py:27)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) p.out_nchw[((long)b * 3 + c) * HW + rem] = t[c];
+      for (int c = 0; c < COUT; ++c) p.out_nchw[((long)b * COUT + c) * HW + rem] = a1[c];
+      continue;
     }
-    if (p.mode == 2) {
-      const float m = p.mask[idx];
-      f32x4 o;
+    if (p.mode == 0) {
+      const float m = sigmoidf_(a1[0]);
+      p.out_nchw[p.out_bs ? (long)b * p.out_bs + rem : idx] = m;
+      if (p.hard) p.hard[idx] = m > 0.5f ? 1.f : 0.f;
+      continue;
+    }
+    if constexpr (COUT == 3) {
+      float t[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        // xnow = stage1*mask + xin*(1-mask), xin = image*(1-mask)   (editline_g.py:124,179-180)
-        const float xin = p.img[((long)b * 3 + c) * HW + rem] * (1.f - m);
-        o[c] = p.no_mask_coarse ? t[c] : t[c] * m + xin * (1.f - m);
-      }
-      o[3] = 0.f;
-      if (BF16) *(uint4*)((char*)p.xnow + idx * 16) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], 0.f), 0u, 0u);
-      else *(f32x4*)(p.xnow + idx * 4) = o;
-    } else if (p.mode == 3 && (p.composed || p.rgb8 || p.m8)) {
-      const float m = p.mask[p.mask_bs ? (long)b * p.mask_bs + rem : idx];
-      const long cb = p.comp_bs ? (long)b * p.comp_bs : (long)b * 3 * HW;
+      for (int c = 0; c < 3; ++c) t[c] = tanh_fast(a1[c]);
+      if (p.out_nchw) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float im = p.img[((long)b * 3 + c) * HW + rem];
-        const float v = t[c] * m + im * (1.f - m);                              // editline2_model.py:132
-        if (p.composed) p.composed[cb + (long)c * HW + rem] = v;
-        // test.py:25-27: (x + 1) / 2 * 255 -> uint8, same fp32 operation order, truncation, no clamp; HWC as test.py:35
-        if (p.rgb8) p.rgb8[idx * 3 + c] = (unsigned char)(int)(((v + 1.f) * 0.5f) * 255.f);
+        for (int c = 0; c < 3; ++c) p.out_nchw[((long)b * 3 + c) * HW + rem] = t[c];
       }
-      if (p.m8) p.m8[idx] = (unsigned char)(int)(m * 255.f);
+      if (p.mode == 2) {
+        const float m = p.mask[idx];
+        f32x4 ov;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          // xnow = stage1*mask + xin*(1-mask), xin = image*(1-mask)   (editline_g.py:124,179-180)
+          const float xin = p.img[((long)b * 3 + c) * HW + rem] * (1.f - m);
+          ov[c] = p.no_mask_coarse ? t[c] : t[c] * m + xin * (1.f - m);
+        }
+        ov[3] = 0.f;
+        if (BF16) *(uint4*)((char*)p.xnow + idx * 16) = make_uint4(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], 0.f), 0u, 0u);
+        else *(f32x4*)(p.xnow + idx * 4) = ov;
+      } else if (p.mode == 3 && (p.composed || p.rgb8 || p.m8)) {
+        const float m = p.mask[p.mask_bs ? (long)b * p.mask_bs + rem : idx];
+        const long cb = p.comp_bs ? (long)b * p.comp_bs : (long)b * 3 * HW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float im = p.img[((long)b * 3 + c) * HW + rem];
+          const float v = t[c] * m + im * (1.f - m);                              // editline2_model.py:132
+          if (p.composed) p.composed[cb + (long)c * HW + rem] = v;
+          // test.py:25-27: (x + 1) / 2 * 255 -> uint8, same fp32 operation order, truncation, no clamp; HWC as test.py:35
+          if (p.rgb8) p.rgb8[idx * 3 + c] = (unsigned char)(int)(((v + 1.f) * 0.5f) * 255.f);
+        }
+        if (p.m8) p.m8[idx] = (unsigned char)(int)(m * 255.f);
+      }
     }
   }
 }
 
-hipError_t launch_small_conv(const SmallConvParams& p, hipStream_t st) {
-  const long n = (long)p.B * p.H * p.W;
-  const int grid = (int)((n + 255) / 256);
+hipError_t launch_small_conv(const SmallConvParams& p0, hipStream_t st) {
+  // the kernel addresses its input through 32-bit byte offsets (buffer loads): batches whose activation reaches 2 GB are
+  // run as several launches over sub-batches, every per-image pointer advanced accordingly
+  const long HW = (long)p0.H * p0.W;
+  const long pxb = p0.bf16 ? 32 : 48;
+  if (HW * pxb >= (1l << 31)) return hipErrorInvalidValue;
+  const int nbmax = (int)(((1l << 31) - 1) / (HW * pxb));
   ProfScope ps_(st, PL_SMALL_CONV);
-  if (p.cout == 1 && !p.bf16)
-    hipLaunchKernelGGL((small_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, p);
-  else if (p.cout == 3 && !p.bf16)
-    hipLaunchKernelGGL((small_conv_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
-  else if (p.cout == 1)
-    hipLaunchKernelGGL((small_conv_kernel<1, true>), dim3(grid), dim3(256), 0, st, p);
-  else if (p.cout == 3)
-    hipLaunchKernelGGL((small_conv_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
-  else
-    return hipErrorInvalidValue;
+  for (int b0 = 0; b0 < p0.B; b0 += nbmax) {
+    SmallConvParams p = p0;
+    p.B = p0.B - b0 < nbmax ? p0.B - b0 : nbmax;
+    p.x = (const float*)((const char*)p0.x + (size_t)b0 * HW * pxb);
+    const long cs = p0.mode == 4 ? p0.cout : (p0.mode == 0 ? 1 : 3);
+    if (p0.out_nchw) p.out_nchw = p0.out_nchw + (size_t)b0 * (p0.out_bs ? p0.out_bs : cs * HW);
+    if (p0.hard) p.hard = p0.hard + (size_t)b0 * HW;
+    if (p0.img) p.img = p0.img + (size_t)b0 * 3 * HW;
+    if (p0.mask) p.mask = p0.mask + (size_t)b0 * (p0.mask_bs ? p0.mask_bs : HW);
+    if (p0.xnow) p.xnow = (float*)((char*)p0.xnow + (size_t)b0 * HW * 16);
+    if (p0.composed) p.composed = p0.composed + (size_t)b0 * (p0.comp_bs ? p0.comp_bs : 3 * HW);
+    if (p0.rgb8) p.rgb8 = p0.rgb8 + (size_t)b0 * HW * 3;
+    if (p0.m8) p.m8 = p0.m8 + (size_t)b0 * HW;
+    const long n = (long)p.B * ((p.H + 3) / 4) * p.W;
+    const int grid = (int)((n + 255) / 256);
+    if (p.cout == 1 && !p.bf16)
+      hipLaunchKernelGGL((small_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, p);
+    else if (p.cout == 3 && !p.bf16)
+      hipLaunchKernelGGL((small_conv_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
+    else if (p.cout == 1)
+      hipLaunchKernelGGL((small_conv_kernel<1, true>), dim3(grid), dim3(256), 0, st, p);
+    else if (p.cout == 3)
+      hipLaunchKernelGGL((small_conv_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
+    else
+      return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
