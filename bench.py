@@ -56,11 +56,13 @@ FLAGS = FLAG_USE_CAM | FLAG_POOL_MAX | FLAG_JOINT_TRAIN_INP   # test_celeb.sh: -
 LIVE_GFLOP_PER_IMAGE = {256: 90.80, 512: 437.27}
 
 # rocprofv3 kernel names -> profiler labels (tools/pmc_summary.py uses the same table)
-KERNEL_LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96",
-                 "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96", "gconv_kernel<3": "gconv_n48",
-                 "gconv_kernel<2": "gconv_n24", "att2_pair_kernel": "att_score", "att2_pv_kernel": "att_pv",
-                 "att2_softmax": "att_softmax", "att2_boxsum_kernel": "att_boxsum",
-                 "att_score_kernel": "att_score", "att_pv_kernel": "att_pv"}
+KERNEL_LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96", "winoup48_kernel": "gconv_n48",
+                 "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96", "gconv_kernel<3": "gconv_n48", "gconv_kernel<2": "gconv_n24",
+                 "rtile_kernel<3": "gconv_n48", "rtile_kernel<2": "gconv_n24", "rconv16": "gconv_n192", "rconv96": "gconv_n96",
+                 "att2_pair_kernel": "att_score", "att2_pv_kernel": "att_pv", "att2_softmax": "att_softmax", "att2_stats": "att_softmax",
+                 "att2_boxsum": "att_boxsum", "att2_ptilde": "att_boxsum", "att2_prep": "att_prep", "att2_transpose": "att_prep",
+                 "att_score_kernel": "att_score", "att_pv_kernel": "att_pv", "small_conv_kernel": "small_conv", "pack_": "pack",
+                 "colreduce": "colreduce"}
 
 
 def cpu_baseline(budget_s=25.0):

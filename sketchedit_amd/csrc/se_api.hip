@@ -1169,16 +1169,18 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
   const bool v2 = attention_v2_enabled() || bf;       // the bf16 path exists in the space-to-depth form only
   const int hc = h / 2, wc = w / 2, R = hc * wc;
   const int Rp = att_row_stride(R, bf);
+  const int guard = (wc + 8 + 63) & ~63;               // floats; att2_ptilde_kernel reads up to wc + 5 columns outside a row
   if (v2 && (double)R * Rp * 4.0 >= 2147483648.0) return P.rc = fail(c, "attention: %dx%d feature map too large", h, w);
   // fp32 scratch is sized in floats whatever the activation type
   float* part = P.alloc_raw((size_t)B * COLREDUCE_SPLITS * 96);
   float* rn = P.alloc_raw((size_t)B * 96);
   float* xn = P.alloc_raw(bf ? ((size_t)B * h * w * 96 + 1) / 2 : (size_t)B * h * w * 96);
-  float *valid = nullptr, *S = nullptr, *S2 = nullptr, *xT = nullptr;
+  float *valid = nullptr, *S = nullptr, *S2 = nullptr, *xT = nullptr, *stats = nullptr;
   if (v2) {
-    valid = P.alloc_raw((size_t)B * Rp);
+    valid = P.alloc_raw(3 * ((size_t)B * Rp + guard));      // validR, kmul, kadd, each behind its guard band
+    stats = P.alloc_raw((size_t)B * R * 2);    // fused streaming pass: (row max, 1 / row sum) per query
     xT = P.alloc_raw(bf ? (size_t)B * 4 * 96 * Rp / 2 : (size_t)B * 4 * 96 * Rp);
-    S = P.alloc_raw((size_t)B * R * Rp);       // E (fp32), then P~ (fp32, or bf16 in its front half)
+    S = P.alloc_raw((size_t)B * R * Rp + 2 * guard);       // E (fp32) between two guard bands; three-pass form: then P~
     S2 = P.alloc_raw(bf ? (size_t)B * R * Rp / 2 : (size_t)B * R * Rp);      // P (fp32 / bf16)
   } else {
     valid = P.alloc_raw((size_t)B * Lp);
@@ -1194,7 +1196,8 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
     a.scale = 10.f; a.th = 0.1f;                        // editline_g.py:35-38
     if (v2) {
       a.hc = hc; a.wc = wc; a.R = R; a.Rp = Rp; a.bf16 = bf ? 1 : 0;
-      a.validR = valid; a.xT = xT; a.E = S; a.P = S2; a.similar = similar_nchw;
+      a.validR = valid + guard; a.xT = xT; a.E = S + guard; a.P = S2; a.stats = stats; a.guard = guard; a.similar = similar_nchw;
+      a.kmul = valid + ((size_t)B * Rp + guard) + guard; a.kadd = valid + 2 * ((size_t)B * Rp + guard) + guard;
       HIPCHK(c, launch_attention(a, c->st));
     } else {
       a.valid = valid; a.S = S;
@@ -1205,7 +1208,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
       }
     }
   }
-  P.release(S2); P.release(S); P.release(xT); P.release(valid);
+  P.release(S2); P.release(S); P.release(xT); P.release(stats); P.release(valid);
   P.release(xn); P.release(rn); P.release(part);
   return 0;
 }
@@ -1687,7 +1690,7 @@ int se_attention_ex(se_ctx* c, void* stream, const float* x, const float* mask_f
   begin_call(c, stream, exec_flags & SE_FLAG_BF16);
   const bool bf = c->bf16;
   const int R = (h / 2) * (w / 2), Rp = att_row_stride(R, true) + 64;
-  const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (1 + 4 * 96) + 64 * 96 * B) * 4 + (1 << 16);
+  const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (3 + 4 * 96) + 64 * 96 * B + 2 * (size_t)B * R + 5 * (size_t)(w / 2 + 72)) * 4 + (1 << 16);
   char* ws = nullptr;
   HIPCHK(c, hipMalloc(&ws, bytes));
   c->arena.reset(ws, bytes, false);

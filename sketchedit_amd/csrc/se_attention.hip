@@ -15,6 +15,10 @@
 
 #include <cstdlib>
 
+#ifndef SE_ATT_FUSED_BF16_DEFAULT
+#define SE_ATT_FUSED_BF16_DEFAULT false
+#endif
+
 namespace se {
 
 __global__ void att_prep_kernel(const AttParams p) {
@@ -373,6 +377,16 @@ __global__ void att2_prep_kernel(const AttParams p) {
       val = mm > p.th ? 1.f : 0.f;
     }
     p.validR[idx] = val;
+    if (p.kmul) {      // the key test of the fused streaming pass in arithmetic form (att2_ptilde4_kernel)
+      p.kmul[idx] = val > 0.f ? p.scale * 1.44269504088896340736f : 0.f;
+      p.kadd[idx] = val >= 0.f ? 0.f : -INFINITY;
+    }
+  }
+  if (idx < p.guard) {      // guard bands: in front of image 0 of the key tables (not a key), around E (finite)
+    p.validR[-1 - idx] = -1.f;
+    if (p.kmul) { p.kmul[-1 - idx] = 0.f; p.kadd[-1 - idx] = -INFINITY; }
+    p.E[-1 - idx] = 0.f;
+    p.E[(size_t)p.B * p.R * p.Rp + idx] = 0.f;
   }
 }
 
@@ -469,16 +483,29 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
     dma_wait_all();
     __syncthreads();
   }
+  // E tile out through LDS (the staging buffers are free after the last barrier): an accumulator holds 4 consecutive keys
+  // of ONE query per lane, so a direct store scatters 64-byte pieces over 16 rows per instruction; transposed, 16 lanes
+  // write one query's 256 contiguous bytes (two full cache lines), 4 rows per store instruction.  Each wave owns a
+  // private [PT*16 queries][NT*16 keys (+4 pad)] fp32 region.
+  constexpr int TS = NT * 16 + 4;                    // padded row stride in floats: breaks the power-of-two bank stride
+  static_assert(4 * PT * 16 * TS * 4 <= 2 * XBYTES + 2 * WBYTES, "transpose buffer exceeds the staging buffers");
+  float* T = (float*)smem + w * (PT * 16 * TS);
   const int q = lane >> 4;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int j = k0 + nt * 16 + q * 4;
-    if (j >= p.Rp) continue;
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int i = q0 + (w * PT + pt) * 16 + (lane & 15);
-      if (i < p.R) *(f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j) = acc[nt][pt];
-    }
+    for (int pt = 0; pt < PT; ++pt) *(f32x4*)(T + (pt * 16 + (lane & 15)) * TS + nt * 16 + q * 4) = acc[nt][pt];
+  // (wave-private region: no barrier, the LDS operations of one wave complete in order)
+  constexpr int PPR = NT * 4;                        // 16-byte pieces per row
+  constexpr int RPI = 64 / PPR;                      // rows per store instruction
+  const int pc = lane % PPR, pr = lane / PPR;
+  const int j = k0 + pc * 4;
+#pragma unroll
+  for (int rr = 0; rr < PT * 16; rr += RPI) {
+    const int row = rr + pr;
+    const f32x4 v = *(const f32x4*)(T + row * TS + pc * 4);
+    const int i = q0 + w * PT * 16 + row;
+    if (i < p.R && j < p.Rp) *(f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j) = v;
   }
 }
 
@@ -743,6 +770,237 @@ __global__ __launch_bounds__(256) void att2_boxsum4_kernel(const AttParams p) {
   }
 }
 
+// =====================================================================================================================
+// Fused form of the two streaming passes (round 3, the default in fp32): P is never written.
+//   att2_stats_kernel : one wave per query i: row maximum and 1 / row sum of the exponentials   (E read once, 8 bytes out)
+//   att2_ptilde_kernel: one wave per class-grid row r: P~[r][s] = sum_d exp(S[r-d][s-d] - m_{r-d}) / l_{r-d}, with
+//                       S[r-d][s-d] = scale * valid[s-d] * sum_{d'} E[r-d+d'][s-d+d'] formed on the fly from the 3 x 3
+//                       neighbourhood T[dl] = E[r+dl][s+dl], dl in {-1,0,1}^2 (row and column shifted TOGETHER).
+// Against the three-pass form (E -> P, P -> P~) this removes one full R x R write and one full read from HBM (P), at
+// the price of 4 exps and 15 (mostly L2-hit) loads per 4 outputs.  S, the normalisation and the order of the four-term
+// sum are those of att2_softmax_reg_kernel + att2_boxsum4_kernel; the exponential is v_exp_f32 instead of ocml's expf
+// (16 of them per 4 outputs: the full-precision routine made the pass VALU-bound), so the two forms agree to ~1e-7
+// relative, not bit for bit.  The three-pass form (SE_ATT_FUSED=0) is kept for `similar_out` (it needs P) and A/B runs.
+// =====================================================================================================================
+// stats[q] = (m2, 1 / l): m2 = max_j t[j], l = sum_j exp2(t[j] - m2), t[j] = fma(sumE[j], kmul[j], kadd[j]) = S[q][j] * log2(e), or
+// -inf where j is not a key (the key tables are described at att2_ptilde4_kernel).
+template <int NV, bool BF16>
+__global__ __launch_bounds__(256) void att2_stats_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  int b, iy, ix;
+  if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hs, p.ws, b, iy, ix)) return;
+  const int r0 = iy * p.wc + ix;
+  const float* E0 = p.E + ((size_t)b * p.R + r0) * p.Rp;
+  const float* E1 = E0 + p.Rp + 1;                             // (iy, ix+1), column shift folded in
+  const float* E2 = E0 + (size_t)p.wc * p.Rp + p.wc;           // (iy+1, ix)
+  const float* E3 = E2 + p.Rp + 1;                             // (iy+1, ix+1)
+  const float* km = p.kmul + (size_t)b * p.Rp;
+  const float* ka = p.kadd + (size_t)b * p.Rp;
+  const int clast = p.Rp - 1;                 // never a key (last class-grid position or a pad column): kadd = -inf there
+  float m = -INFINITY, sum = 0.f;
+  if constexpr (NV > 0) {                     // the whole row in registers: E is read once
+    float v[NV];
+    // Every load is unconditional (clamped index) and the loads of 16 columns are issued as one batch in front of a
+    // scheduling barrier: left alone, hipcc emits load / wait / add for each operand of each column in turn and the
+    // pass is latency-bound.
+    constexpr int BATCH = 16;
+#pragma unroll
+    for (int k0 = 0; k0 < NV; k0 += BATCH) {
+      float a0[BATCH], a1[BATCH], a2[BATCH], a3[BATCH], mu[BATCH], ad[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int sl = min(lane + 64 * (k0 + j), clast);
+        mu[j] = km[sl];
+        ad[j] = ka[sl];
+        a0[j] = E0[sl];
+        a1[j] = E1[sl];
+        a2[j] = E2[sl];
+        a3[j] = E3[sl];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        v[k0 + j] = fmaf(((a0[j] + a1[j]) + a2[j]) + a3[j], mu[j], ad[j]);
+        m = fmaxf(m, v[k0 + j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sum += __builtin_amdgcn_exp2f(v[k] - m);
+    // (columns >= Rp were clamped onto the never-a-key column Rp - 1: -inf, exp2 gives 0)
+  } else {                                    // rows that do not fit in registers: two sweeps
+    auto tval = [&](int s) { return fmaf(((E0[s] + E1[s]) + E2[s]) + E3[s], km[s], ka[s]); };
+    for (int s = lane; s < p.Rp; s += 64) m = fmaxf(m, tval(s));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int s = lane; s < p.Rp; s += 64) sum += __builtin_amdgcn_exp2f(tval(s) - m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) *(float2*)(p.stats + ((size_t)b * p.R + r0) * 2) = make_float2(m, 1.f / sum);
+}
+
+// No per-lane clamps or range tests: E and the key tables are allocated with guard bands (AttParams::guard floats in
+// front of and behind E -- zero-filled -- and in front of validR / kmul / kadd), a shifted column that leaves its row
+// lands in a neighbouring row or in a guard, and every such (finite) value only feeds a term whose key test fails.
+// The key test is arithmetic: kmul[s] = scale * log2(e) for a valid key, 0 for an invalid one (multiplicative zero,
+// splitcam.py:90,104) or a position that is not a key; kadd[s] = 0 for a key, -inf otherwise, so that
+//   P[r-d][s-d] = exp2(fma(sumE, kmul, kadd - m log2 e)) / l   is exactly 0 where s - d is not a key.
+// The exponentials run on v_exp_f32 (~1 ulp; att2_stats_kernel forms the row sums with the same expression, so the
+// probabilities of a row still sum to 1 to rounding).
+//
+// att2_ptilde4_kernel (wc % 4 == 0: every standard size): four adjacent columns per lane.  What bounds this pass is VALU
+// issue (16 S values, 16 exponentials and 16 scalings per lane and group), so everything that is not an exponential
+// is PACKED two columns per instruction (v_pk_add / v_pk_fma / v_pk_mul_f32), which needs every operand as an aligned
+// register pair (column 2k, column 2k+1).  The column-shifted operands E[.][s0 - 1 ..] and E[.][s0 + 1 ..] are therefore
+// fetched by their own 16-byte loads at 4-byte-aligned addresses (the texture path splits such a load in two, and has
+// the room: 13 loads per group against ~150 VALU issue slots) instead of being assembled from an aligned group and a
+// neighbour element (lane shifts or strided element loads were measured: the re-pairing moves cost more than the loads).
+template <bool BF16>
+__global__ __launch_bounds__(512) void att2_ptilde4_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int b, ry, rx;
+  // a block = 8 waves = a 2 x 4 patch of class-grid rows (two blocks side by side, four pairs of grid rows = one 8 x 8 tile
+  // of tile_order): its 24 source rows of E, 1 KB each per column step, fit the CU's 32 KB vector L1, and the waves are
+  // kept in step (barrier per step) so that a row one wave pulls in is a hit for the others -- the pass is bound by the
+  // L2 -> L1 traffic of its nine source rows per output row, not by HBM, VALU issue or instruction count (all three were
+  // varied without effect).
+  const int blk = xcd_tile(blockIdx.x, gridDim.x);
+  const long q = (long)(blk >> 3) * 64 + ((blk >> 1) & 3) * 16 + (wv >> 2) * 8 + (blk & 1) * 4 + (wv & 3);
+  const bool live = tile_order(q, p.B, p.hc, p.wc, b, ry, rx);
+  if (!live) { b = 0; ry = 0; rx = 0; }        // padding wave of a ragged tile: walks row 0 in step with the block, stores nothing
+  const int r = ry * p.wc + rx;
+  constexpr int ES = BF16 ? 2 : 4;
+  const float* Eb = p.E + (size_t)b * p.R * p.Rp;
+  const float* km = p.kmul + (size_t)b * p.Rp;
+  const float* ka = p.kadd + (size_t)b * p.Rp;
+  char* out = (char*)p.P + ((size_t)b * p.R + r) * p.Rp * ES;
+  // the four queries r - d that own a patch covering class-grid pixel r (wave-uniform): validity, -m2, 1 / sum
+  bool okq[4];
+  float mq[4], iq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int dy = d >> 1, dx = d & 1, qy = ry - dy, qx = rx - dx;
+    okq[d] = qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;
+    const float2 st = *(const float2*)(p.stats + ((size_t)b * p.R + (okq[d] ? qy * p.wc + qx : 0)) * 2);
+    mq[d] = -st.x; iq[d] = st.y;
+  }
+  // rows r + dly * wc + dlx of E with their column shift folded into the pointer: rowp[a][c][s] = E[r + dl][s + dl]; a row
+  // index outside the matrix is clamped (it only ever feeds a term of a query that does not exist)
+  const float* rowp[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int dl = (a - 1) * p.wc + (c - 1);
+      rowp[a][c] = Eb + (size_t)min(max(r + dl, 0), p.R - 1) * p.Rp + dl;
+    }
+  struct Grp {
+    f32x4 t[3][3];          // t[a][c][u] = E[r + dl][s0 + u + dl]
+    f32x4 m[4], ad[4];      // kmul / kadd of key s0 + u - off_d
+  };
+  auto load = [&](int s0, Grp& g) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g.t[a][c] = *(const f32x4*)(rowp[a][c] + s0);      // c = 1: 16-byte aligned; c = 0, 2: 4-byte aligned
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int off = (d >> 1) * p.wc + (d & 1);
+      g.m[d] = *(const f32x4*)(km + s0 - off);
+      g.ad[d] = *(const f32x4*)(ka + s0 - off);
+    }
+  };
+  auto compute = [&](int s0, const Grp& g) {
+    f32x2 acc[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (!okq[d]) continue;                   // wave-uniform
+      const int dy = d >> 1, dx = d & 1;
+      const f32x2 mm = (f32x2){mq[d], mq[d]}, ii = (f32x2){iq[d], iq[d]};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {            // column pairs (0,1), (2,3)
+        auto pr = [&](const f32x4& v) { return (f32x2){v[2 * h], v[2 * h + 1]}; };
+        // the 2 x 2 block of T that forms S[r - d][s - d] (dl = d' - d, d' in {0,1}^2), summed in the order E0 + E1 + E2 + E3 of
+        // the softmax kernels
+        const f32x2 sum = ((pr(g.t[1 - dy][1 - dx]) + pr(g.t[1 - dy][2 - dx])) + pr(g.t[2 - dy][1 - dx])) + pr(g.t[2 - dy][2 - dx]);
+        const f32x2 arg = sum * pr(g.m[d]) + (pr(g.ad[d]) + mm);
+        f32x2 pv = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} * ii;
+        if (BF16) {                            // P is a bf16 value in bf16 mode (rounded before the sum)
+          const unsigned u = pack_bf16x2(pv[0], pv[1]);
+          pv = (f32x2){bf16_lo(u), bf16_hi(u)};
+        }
+        acc[h] += pv;
+      }
+    }
+    if (s0 >= p.Rp || !live) return;
+    if (BF16) *(uint2*)(out + s0 * 2) = make_uint2(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1]));
+    else *(f32x4*)(out + s0 * 4) = (f32x4){acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+  };
+  // one column group per lane and step (a second group in flight was measured: no gain, and it doubles the L1 footprint)
+  Grp g;
+  for (int s0 = 4 * lane; s0 < p.Rp; s0 += 256) {
+    load(s0, g);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s0, g);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+}
+
+// any wc: one column per lane, element loads, the same arithmetic unpacked
+template <bool BF16>
+__global__ __launch_bounds__(256) void att2_ptilde1_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  int b, ry, rx;
+  if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hc, p.wc, b, ry, rx)) return;
+  const int r = ry * p.wc + rx;
+  constexpr int ES = BF16 ? 2 : 4;
+  const float* Eb = p.E + (size_t)b * p.R * p.Rp;
+  const float* km = p.kmul + (size_t)b * p.Rp;
+  const float* ka = p.kadd + (size_t)b * p.Rp;
+  char* out = (char*)p.P + ((size_t)b * p.R + r) * p.Rp * ES;
+  bool okq[4];
+  float mq[4], iq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int dy = d >> 1, dx = d & 1, qy = ry - dy, qx = rx - dx;
+    okq[d] = qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;
+    const float2 st = *(const float2*)(p.stats + ((size_t)b * p.R + (okq[d] ? qy * p.wc + qx : 0)) * 2);
+    mq[d] = -st.x; iq[d] = st.y;
+  }
+  const float* rowp[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int dl = (a - 1) * p.wc + (c - 1);
+      rowp[a][c] = Eb + (size_t)min(max(r + dl, 0), p.R - 1) * p.Rp + dl;
+    }
+  for (int s0 = lane; s0 < p.Rp; s0 += 64) {
+    float t[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) t[a][c] = rowp[a][c][s0];
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (!okq[d]) continue;
+      const int dy = d >> 1, dx = d & 1, off = dy * p.wc + dx;
+      const float sum = ((t[1 - dy][1 - dx] + t[1 - dy][2 - dx]) + t[2 - dy][1 - dx]) + t[2 - dy][2 - dx];
+      float pv = __builtin_amdgcn_exp2f(sum * km[s0 - off] + (ka[s0 - off] + mq[d])) * iq[d];
+      if (BF16) pv = bf16_lo(pack_bf16x2(pv, 0.f) & 0xffffu);
+      acc += pv;
+    }
+    if (BF16) *(unsigned short*)(out + s0 * 2) = (unsigned short)(pack_bf16x2(acc, 0.f) & 0xffffu);
+    else *(float*)(out + s0 * 4) = acc;
+  }
+}
+
 // out[b, 2r + cls, c] = sum_s P~[r][s] * xT[cls][c][s]: A tile = 96 channel rows x 32 keys, MFMA columns = class-grid pixels
 template <int PT, bool BF16>
 __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
@@ -763,7 +1021,7 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
   const int nt_ = (p.R + PIX - 1) / PIX;
   const int b = (lb >> 2) / nt_, t0 = ((lb >> 2) - b * nt_) * PIX;
   const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
-  const se_i32x4 rs_P = make_rsrc((const char*)p.E + (size_t)b * p.R * p.Rp * ES, (unsigned)p.R * p.Rp * (unsigned)ES);
+  const se_i32x4 rs_P = make_rsrc((const char*)p.Pt + (size_t)b * p.R * p.Rp * ES, (unsigned)p.R * p.Rp * (unsigned)ES);
   const se_i32x4 rs_V = make_rsrc((const char*)p.xT + ((size_t)b * 4 + cls) * 96 * p.Rp * ES, 96u * p.Rp * (unsigned)ES);
   unsigned xo[NX], wo[NW];
 #pragma unroll
@@ -832,8 +1090,29 @@ __global__ void att2_similar_kernel(const AttParams p) {
   p.similar[idx] = BF16 ? bf16_lo(((const unsigned short*)p.P)[at]) : p.P[at];
 }
 
+// Which form runs (measured on MI355X, round 3, profiles/r03_*):
+//   256x256 inputs (R = 1024):  fused 44 + 100 us  vs  three-pass 75 + 76 us  per 32 images   -> fused
+//   512x512 inputs (R = 4096):  fused 189 + 426 us vs  three-pass 282 + 285 us per 8 images   -> three-pass (the fused pass
+//       moves 0.4 GB less through HBM -- 3.6 instead of 4.0 GB per step -- but is bound by the L2 -> L1 traffic of its nine
+//       source rows per output row; an LDS-staged tile form is what would fix that, not built)
+//   bf16: P is bf16 there, so the fused form saves no bytes (E is read twice instead of E + P once each) and measured slower.
+// SE_ATT_FUSED=0 / 1 forces the three-pass / fused form in fp32 (default: fused for R <= 1024); SE_ATT_FUSED_BF16=1 extends the
+// choice to bf16 mode.
+static bool att_fused(bool bf16, int Rp) {
+  // (read per call, not cached: the tests switch forms inside one process)
+  const char* e1 = getenv("SE_ATT_FUSED");
+  const char* e2 = getenv("SE_ATT_FUSED_BF16");
+  const int f32mode = e1 ? (atoi(e1) != 0 ? 1 : 0) : -1;
+  const bool bfon = e2 ? atoi(e2) != 0 : SE_ATT_FUSED_BF16_DEFAULT;
+  if (bf16 && !bfon) return false;
+  return f32mode < 0 ? Rp <= 1024 : f32mode == 1;
+}
+
 template <bool BF16>
-static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
+static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
+  AttParams p = p0;
+  const bool fused = att_fused(BF16, p.Rp) && !p.similar && p.stats;      // `similar_out` is P itself: three-pass form
+  p.Pt = fused ? p.P : p.E;
   {
     const long n = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);
     ProfScope ps_(st, PL_ATT_PREP);
@@ -852,24 +1131,42 @@ static hipError_t launch_attention_v2_t(const AttParams& p, hipStream_t st) {
     ProfScope ps_(st, PL_ATT_SCORE);
     hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
   }
-  {
-    const long rows = tile_order_count(p.B, p.hs, p.ws);
-    ProfScope ps_(st, PL_ATT_SOFTMAX);
-    const dim3 grid((unsigned)((rows + 3) / 4));
-    if (p.Rp <= 64 * 16) hipLaunchKernelGGL((att2_softmax_reg_kernel<16, BF16>), grid, dim3(256), 0, st, p);
-    else if (p.Rp <= 64 * 64) hipLaunchKernelGGL((att2_softmax_reg_kernel<64, BF16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(att2_softmax_kernel<BF16>, grid, dim3(256), 0, st, p);
-  }
-  if (p.similar) {
-    const long n = (long)p.B * p.L * p.L;
-    ProfScope ps_(st, PL_LAYOUT);
-    hipLaunchKernelGGL(att2_similar_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
-  }
-  {
-    const long rows = tile_order_count(p.B, p.hc, p.wc);
-    ProfScope ps_(st, PL_ATT_BOXSUM);
-    if (p.wc % 4 == 0) hipLaunchKernelGGL(att2_boxsum4_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  if (fused) {
+    {
+      const long rows = tile_order_count(p.B, p.hs, p.ws);
+      ProfScope ps_(st, PL_ATT_SOFTMAX);
+      const dim3 grid((unsigned)((rows + 3) / 4));
+      if (p.Rp <= 64 * 16) hipLaunchKernelGGL((att2_stats_kernel<16, BF16>), grid, dim3(256), 0, st, p);
+      else if (p.Rp <= 64 * 64) hipLaunchKernelGGL((att2_stats_kernel<64, BF16>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((att2_stats_kernel<0, BF16>), grid, dim3(256), 0, st, p);
+    }
+    {
+      const long rows = tile_order_count(p.B, p.hc, p.wc);
+      ProfScope ps_(st, PL_ATT_BOXSUM);
+      const dim3 grid((unsigned)((rows + 3) / 4));
+      if (p.wc % 4 == 0) hipLaunchKernelGGL((att2_ptilde4_kernel<BF16>), dim3((unsigned)((rows + 7) / 8)), dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((att2_ptilde1_kernel<BF16>), grid, dim3(256), 0, st, p);
+    }
+  } else {
+    {
+      const long rows = tile_order_count(p.B, p.hs, p.ws);
+      ProfScope ps_(st, PL_ATT_SOFTMAX);
+      const dim3 grid((unsigned)((rows + 3) / 4));
+      if (p.Rp <= 64 * 16) hipLaunchKernelGGL((att2_softmax_reg_kernel<16, BF16>), grid, dim3(256), 0, st, p);
+      else if (p.Rp <= 64 * 64) hipLaunchKernelGGL((att2_softmax_reg_kernel<64, BF16>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(att2_softmax_kernel<BF16>, grid, dim3(256), 0, st, p);
+    }
+    if (p.similar) {
+      const long n = (long)p.B * p.L * p.L;
+      ProfScope ps_(st, PL_LAYOUT);
+      hipLaunchKernelGGL(att2_similar_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    }
+    {
+      const long rows = tile_order_count(p.B, p.hc, p.wc);
+      ProfScope ps_(st, PL_ATT_BOXSUM);
+      if (p.wc % 4 == 0) hipLaunchKernelGGL(att2_boxsum4_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    }
   }
   {
     constexpr int PT = 4;

@@ -6,6 +6,7 @@
 namespace se {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DEVFN __device__ __forceinline__
 
 // ---- LDS-DMA ------------------------------------------------------------------------------------

@@ -250,8 +250,14 @@ struct AttParams {
   // ---- space-to-depth form (se_attention.hip, "v2"): class grid hc x wc = h/2 x w/2, R = hc*wc rows, Rp = R rounded up to 32
   int hc, wc, R, Rp;
   float* xT;           // [B][4 classes][96][Rp]  workspace: x transposed per parity class (A operand of the P~.V GEMM)
-  float* E;            // [B][R][Rp] workspace: pixel-pair dot products E, later overwritten by P~
-  float* P;            // [B][R][Rp] workspace (fp32, or bf16 in bf16 mode): softmax probabilities in class-grid indexing (row = query, column = key)
+  float* E;            // [B][R][Rp] workspace: pixel-pair dot products E (three-pass form: later overwritten by P~)
+  float* P;            // [B][R][Rp] workspace (fp32, or bf16 in bf16 mode): softmax probabilities in class-grid indexing (row = query,
+                       // column = key); fused form: P~ is written here directly and P never exists
+  float* Pt;           // where att2_pv_kernel reads P~: E (three-pass form) or P (fused form)
+  float* stats;        // [B][R][2] fused form: row maximum and 1 / row sum of every query, in class-grid indexing
+  float* kmul;         // [B][Rp] fused form: scale * log2(e) for a valid key, 0 for an invalid key or a non-key position
+  float* kadd;         // [B][Rp] fused form: 0 for a key, -inf for a position that is not a key
+  int guard;           // floats of guard band allocated in front of and behind E and in front of validR (>= wc + 8)
   float* validR;       // [B][Rp]    workspace: key validity in class-grid indexing: 1 / 0, -1 where the position is not a key
   float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
   int bf16;            // x, xn, xT, P~ (in the E buffer) and out hold bf16; Rp is then a multiple of 64

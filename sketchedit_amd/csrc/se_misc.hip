@@ -81,7 +81,6 @@ ProfScope::~ProfScope() {
 //     the end) -- half the VALU issue slots;
 //   * blocks are handed to the XCDs in contiguous ranges (xcd_tile), so the two halo rows a strip shares with its
 //     vertical neighbours come out of the same L2.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int COUT, bool BF16>
 __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p) {
   constexpr int SR = 4;                       // output rows per lane (a ragged last strip is masked)

@@ -224,6 +224,34 @@ def test_op_attention_soft_scores_vs_oracle(eng, shape):
     assert _md(out, ro) < (1e-5 if h < 100 else 1e-4) * float(ro.abs().max())      # up to 4L products per output
 
 
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 24, 40), (2, 64, 64), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
+def test_op_attention_fused_streaming_pass(eng, shape, bf16, monkeypatch):
+    """The fused form of the two streaming passes (att2_stats_kernel + att2_ptilde*_kernel: P is never written) against the
+    oracle AND against the three-pass form, forced on at every size: 16x12 (wc = 6: element-load kernel), 16x16 / 24x40 /
+    64x64 (packed four-column kernel; 64x64 is the 256x256-input size where it is the default), 132x136 (rows that do not
+    fit in registers: two-sweep statistics).  Soft (non-saturated) scores, mixed key validity."""
+    from oracle import sketchedit_oracle as O
+    B, h, w = shape
+    x = 0.004 * synth.uniform(5, "att96s.x%d" % h, (B, 96, h, w), -1, 1)
+    full = (synth.uniform(5, "att96s.m%d" % h, (B, 1, 4 * h, 4 * w), 0, 1) < 0.5).astype(np.float32)
+    full[0, :, :, 2 * w:] = 1.0
+    monkeypatch.setenv("SE_ATT_FUSED", "1")
+    monkeypatch.setenv("SE_ATT_FUSED_BF16", "1")
+    fused = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
+    monkeypatch.setenv("SE_ATT_FUSED", "0")
+    three = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
+    if bf16:
+        ro, _ = O.contextual_attention(torch.from_numpy(x).to(torch.bfloat16).float(), torch.from_numpy(full), torch.bfloat16)
+        tol = 2.0 ** -7 * float(ro.abs().max())
+        assert _md(fused, ro) < tol and _md(fused, three) < tol
+    else:
+        ro, _ = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
+        tol = (1e-5 if h < 100 else 1e-4) * float(ro.abs().max())
+        assert _md(fused, ro) < tol
+        assert _md(fused, three) < 1e-5 * float(ro.abs().max())       # v_exp_f32 vs expf: ~1e-7 relative per probability
+
+
 def test_op_attention_vs_oracle(eng):
     from oracle import sketchedit_oracle as O
     x = synth.uniform(5, "att96.x", (2, 96, 12, 16), -1, 1)
