@@ -442,6 +442,11 @@ def main():
                                      "tflops_executed": round(r["flops_executed"] / (r["total_ms"] * 1e-3) / 1e12, 1)}
                         for r in full_rep["layers"]} if args.layers else None),
             "forward_tflops_live": (LIVE_GFLOP_PER_IMAGE.get(S, 0) * images / elapsed / 1e3) or None,
+            # reference-defined FLOPs of the live forward / wall time, against the MFMA peak of the dtype: the ALGORITHMIC
+            # fraction of the whole step (> executed fraction where Winograd / sub-pixel forms run; the figure to watch at
+            # batch 1, where the low-latency mode runs every layer in its direct form)
+            "forward_algorithmic_frac": (round(LIVE_GFLOP_PER_IMAGE[S] * images / elapsed / 1e3 / peak / world, 4)
+                                         if S in LIVE_GFLOP_PER_IMAGE else None),
         }
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:

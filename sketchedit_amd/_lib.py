@@ -187,6 +187,7 @@ class Engine:
         self._graph_stream = None
         self.precision = "f32"     # "bf16": BASELINE config 5 (bf16 storage + MFMA, fp32 accumulate); see set_precision
         self._static = {}          # graph mode: per-shape input copies and output buffers (stable pointers)
+        self._graph_lock = threading.Lock()    # graph mode is single-caller per Engine: one replay at a time
 
     def close(self):
         if getattr(self, "h", None):
@@ -230,7 +231,8 @@ class Engine:
                     # from handing it out before they finish
                     self._ws.record_stream(self._ws_stream)
                 self._ws = torch.empty(need, dtype=torch.uint8, device="cuda:%d" % self.device)
-                self._static.clear()       # captured graphs are keyed by the workspace pointer
+                with self._graph_lock:     # (never taken in the other order: the graph path asks for the workspace first)
+                    self._static.clear()   # captured graphs are keyed by the workspace pointer
             elif self._ws_stream is not None and self._ws_stream != cur:
                 # one workspace = one stream: forwards on another stream must not overlap the previous ones
                 cur.wait_stream(self._ws_stream)
@@ -292,6 +294,9 @@ class Engine:
         same shape."""
         import torch
         _check_dev(image, sketch)
+        if graph and out is not None:
+            raise SketchEditHipError("graph=True replays into buffers the Engine keeps per shape: `out=` cannot be honoured "
+                                     "(copy from the returned tensors, or call without graph=True)")
         B, _, H, W = image.shape
         ws = self.workspace(B, H, W)
         dev = image.device
@@ -305,26 +310,34 @@ class Engine:
             return o
 
         if graph:
-            key = (B, H, W, bool(visualize))
-            st = self._static.get(key)
-            if st is None:
-                st = self._static[key] = {"image": torch.empty_like(image), "sketch": torch.empty_like(sketch),
-                                          "outs": new_outputs()}
-            st["image"].copy_(image)
-            st["sketch"].copy_(sketch)
-            image, sketch = st["image"], st["sketch"]
-            r = dict(st["outs"])
-        else:
-            r = new_outputs(out)
-        def call(stream):
-            if self.lib.se_inference(self.h, stream, _ptr(image), _ptr(sketch), _ptr(r["composed"]), _ptr(r["mask"]),
-                                     _ptr(r.get("hard")), _ptr(r.get("maskim")), _ptr(r.get("coarse")), _ptr(r.get("fine")),
-                                     _ptr(ws), ws.numel(), B, H, W, flags):
-                self._err("se_inference")
+            # the per-shape input copies, the launch and the (shared) output buffers form one critical section: two threads
+            # replaying the same shape would otherwise overwrite each other's inputs / read each other's outputs.  The
+            # returned tensors ARE the static buffers, so a second graph call of the same shape must wait until the first
+            # caller has consumed them: graph mode is documented single-caller, the lock only keeps a concurrent call from
+            # corrupting a replay in flight.
+            with self._graph_lock:
+                return self._inference_graph(image, sketch, flags, visualize, ws, B, H, W, new_outputs)
+        r = new_outputs(out)
+        self._call_inference(image, sketch, r, ws, B, H, W, flags, self._stream())
+        return r
 
-        if not graph:
-            call(self._stream())
-            return r
+    def _call_inference(self, image, sketch, r, ws, B, H, W, flags, stream):
+        if self.lib.se_inference(self.h, stream, _ptr(image), _ptr(sketch), _ptr(r["composed"]), _ptr(r["mask"]),
+                                 _ptr(r.get("hard")), _ptr(r.get("maskim")), _ptr(r.get("coarse")), _ptr(r.get("fine")),
+                                 _ptr(ws), ws.numel(), B, H, W, flags):
+            self._err("se_inference")
+
+    def _inference_graph(self, image, sketch, flags, visualize, ws, B, H, W, new_outputs):
+        import torch
+        key = (B, H, W, bool(visualize))
+        st = self._static.get(key)
+        if st is None:
+            st = self._static[key] = {"image": torch.empty_like(image), "sketch": torch.empty_like(sketch),
+                                      "outs": new_outputs()}
+        st["image"].copy_(image)
+        st["sketch"].copy_(sketch)
+        image, sketch = st["image"], st["sketch"]
+        r = dict(st["outs"])
         # stream capture is not permitted on the legacy default stream: graph-mode forwards run on a stream of their
         # own, ordered after / before the caller's current stream
         cur = torch.cuda.current_stream(self.device)
@@ -332,7 +345,7 @@ class Engine:
             self._graph_stream = torch.cuda.Stream(device=self.device)
         gs = self._graph_stream
         gs.wait_stream(cur)
-        call(ctypes.c_void_p(gs.cuda_stream))
+        self._call_inference(image, sketch, r, ws, B, H, W, flags, ctypes.c_void_p(gs.cuda_stream))
         cur.wait_stream(gs)
         return r
 

@@ -151,7 +151,10 @@ struct se_ctx {
     std::vector<long long> key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipStream_t stream = nullptr;        // stream of the last launch: synchronised before the exec is destroyed
+    unsigned long long last_use = 0;     // LRU stamp
   };
+  unsigned long long graph_clock = 0;
   std::vector<GraphEntry> graphs;                     // SE_FLAG_GRAPH: captured forwards, keyed by every argument
 };
 
@@ -1267,12 +1270,27 @@ void begin_call(se_ctx* c, void* stream, int flags) {
   set_profiler(&c->prof);
 }
 
-void drop_graphs(se_ctx* c) {
-  for (auto& g : c->graphs) {
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (g.graph) (void)hipGraphDestroy(g.graph);
+// A captured forward may still be executing on the stream it was last launched on: destroying an in-flight hipGraphExec
+// is not safe on every ROCm version, so that stream is drained first (eviction and weight reloads are rare events).
+void destroy_graph(se_ctx::GraphEntry& g) {
+  if (g.exec) {
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+    (void)hipGraphExecDestroy(g.exec);
   }
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr; g.graph = nullptr;
+}
+void drop_graphs(se_ctx* c) {
+  for (auto& g : c->graphs) destroy_graph(g);
   c->graphs.clear();
+}
+// cache full: evict the ONE least recently used entry (hot graphs survive callers that pass fresh output tensors)
+void evict_lru_graph(se_ctx* c) {
+  size_t lru = 0;
+  for (size_t i = 1; i < c->graphs.size(); ++i)
+    if (c->graphs[i].last_use < c->graphs[lru].last_use) lru = i;
+  destroy_graph(c->graphs[lru]);
+  c->graphs.erase(c->graphs.begin() + lru);
 }
 
 }  // namespace
@@ -1395,8 +1413,11 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
         for (int bf = 0; bf < 2; ++bf) {      // (bf16 activations are smaller, but its attention scratch need not be)
           const int flags = (cam ? SE_FLAG_USE_CAM : 0) | (joint ? SE_FLAG_JOINT_TRAIN_INP : 0) | (ll ? SE_FLAG_LOW_LATENCY : 0) |
                             (bf ? SE_FLAG_BF16 : 0) | SE_FLAG_POOL_MAX;
-          const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, true);
-          if (pk.main + pk.side > peak) peak = pk.main + pk.side;
+          // with and without netM's image decoder (mode='visualize' vs 'inference'): two allocation sequences
+          for (int mi = 0; mi < 2; ++mi) {
+            const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, mi != 0);
+            if (pk.main + pk.side > peak) peak = pk.main + pk.side;
+          }
         }
   return peak + 2 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes
 }
@@ -1478,12 +1499,14 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   for (auto& g : c->graphs)
     if (g.key == key) { ge = &g; break; }
   if (!ge) {
-    if (c->graphs.size() >= 16) drop_graphs(c);
+    if (c->graphs.size() >= 16) evict_lru_graph(c);
     c->graphs.emplace_back();
     c->graphs.back().key = key;
+    c->graphs.back().last_use = ++c->graph_clock;
     return enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out, fine_out, ws,
                              ws_bytes, B, H, W, flags);
   }
+  ge->last_use = ++c->graph_clock;
   if (!ge->exec) {
     if (!stream) return fail(c, "SE_FLAG_GRAPH needs a non-default stream (capture is not permitted on the legacy stream)");
     HIPCHK(c, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
@@ -1498,6 +1521,8 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
     if (e2 != hipSuccess) { (void)hipGraphDestroy(graph); return fail(c, "hipGraphInstantiate failed: %s", hipGetErrorString(e2)); }
     ge->graph = graph; ge->exec = exec;
   }
+  ge->stream = (hipStream_t)stream;
+  ge->last_use = ++c->graph_clock;
   HIPCHK(c, hipGraphLaunch(ge->exec, (hipStream_t)stream));
   return 0;
 }

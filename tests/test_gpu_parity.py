@@ -408,6 +408,30 @@ def test_shard_of_a_global_batch_runs_in_the_global_mode(eng_w):
     assert torch.equal(comp, full["composed"]) and torch.equal(mask, full["mask"])
 
 
+def test_graph_mode_refuses_caller_outputs_and_survives_cache_eviction(eng_w):
+    """`out=` cannot be honoured by a graph replay (error, not silence); the library's graph cache evicts ONE least
+    recently used entry when full (17+ distinct argument sets), draining its stream first, and the hot entry keeps working."""
+    from sketchedit_amd._lib import SketchEditHipError
+    img, sk = synth.make_inputs(1, 32, 32, seed=9)
+    ci, cs = _cuda(img), _cuda(sk)
+    out = {"composed": torch.empty((1, 3, 32, 32), device="cuda"), "mask": torch.empty((1, 1, 32, 32), device="cuda")}
+    with pytest.raises(SketchEditHipError):
+        eng_w.inference(ci, cs, FLAGS, out=out, graph=True)
+    want = eng_w.inference(ci, cs, FLAGS, low_latency=True)
+    hot = [eng_w.inference(ci, cs, FLAGS, low_latency=True, graph=True) for _ in range(3)][-1]      # captured on the 2nd call
+    assert torch.equal(hot["composed"], want["composed"])
+    # 20 more argument sets (other shapes -> other static buffers -> other keys), each seen twice so that it is captured
+    for k in range(20):
+        i2, s2 = synth.make_inputs(1, 16, 16 + 8 * k, seed=k)
+        for _ in range(2):
+            eng_w.inference(_cuda(i2), _cuda(s2), FLAGS, low_latency=True, graph=True)
+        if k % 5 == 0:                         # the hot entry stays in use: LRU keeps it
+            hot = eng_w.inference(ci, cs, FLAGS, low_latency=True, graph=True)
+            assert torch.equal(hot["composed"], want["composed"])
+    hot = eng_w.inference(ci, cs, FLAGS, low_latency=True, graph=True)
+    assert torch.equal(hot["composed"], want["composed"]) and torch.equal(hot["mask"], want["mask"])
+
+
 def test_graph_replay_follows_new_inputs(eng_w):
     """A captured forward is replayed on whatever the (stable) input buffers hold: three different inputs through the
     same graph give exactly the eager results of the same mode."""
