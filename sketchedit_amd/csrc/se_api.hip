@@ -77,6 +77,8 @@ struct Layer {
   int nch16 = 0, CGp16 = 0;
   float* d_w16s = nullptr;    // 96 -> 192 3x3 only: the 32-k step image of the 8 x 16 raw-tile kernel (se_rconv16.hip)
   float* d_w96 = nullptr;     // 96-row stride-1 layers: the 32-k step image of se_rconv96.hip
+  float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
+  int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
 
 // ---- workspace arena: first-fit free list over [0, cap) in bytes, 256-B aligned ------------------
@@ -274,6 +276,28 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
   if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
   if (winoup48_eligible_layer(d) && Cp == d.cin) return pack_winoup48(c, L);
+  return 0;
+}
+
+// Dense-K image of a 5x5 first layer (se_rtile.hip rtile_dense5_kernel): k = tap * cin + channel, no channel padding;
+// rows in the MIXED order of the N=48 configuration, slot swizzle as pack_layer.
+int pack_layer_dense(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  const int G = d.cout / 2, NP = 48, T = d.k * d.k, K = T * d.cin, nch = (K + 31) / 32;
+  std::vector<float> img((size_t)nch * NP * 32, 0.f);
+  for (int n = 0; n < NP; ++n) {
+    const int oc = out_channel_of_row(GC_N48, n, G, d.cout);
+    if (oc < 0) continue;
+    for (int kf = 0; kf < K; ++kf) {
+      const int tap = kf / d.cin, ic = kf % d.cin, ty = tap / d.k, tx = tap % d.k;
+      const int ch = kf / 32, kin = kf % 32, s_ = kin / 4, e = kin % 4, ps = s_ ^ ((n >> 1) & 7);
+      img[((size_t)ch * NP + n) * 32 + ps * 4 + e] = L.w[(((size_t)oc * d.cin + ic) * d.k + ty) * d.k + tx];
+    }
+  }
+  if (L.d_wd) (void)hipFree(L.d_wd);
+  HIPCHK(c, hipMalloc(&L.d_wd, img.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_wd, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  L.dense = d.cin; L.nchd = nch;
   return 0;
 }
 
@@ -634,6 +658,8 @@ int pack_net_layer(se_ctx* c, Layer& L) {
     if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && pack_rconv16(c, L)) return 1;
     if (rconv96_eligible(d) && pack_rconv96(c, L)) return 1;
   }
+  // 5x5 first layers whose stored input has padding channels (5 of 8, 3 of 4): dense-K image beside the padded one
+  if (d.k == 5 && d.stride == 1 && d.rate == 1 && d.cout == 48 && (d.cin == 5 || d.cin == 3) && pack_layer_dense(c, L)) return 1;
   std::vector<int> m;
   if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
   else m = identity_map(d.cin);
@@ -666,6 +692,22 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   const int CG = bf ? L.CGp16 : L.CGp, nch = bf ? L.nch16 : L.nch;
   const float* wimg = bf ? L.d_w16 : L.d_w;
   if (!wimg || C0 != CG * gran) return 0;
+  // dense-K form of the 5x5 first layers (fp32): SE_RTILE_DENSE=0 keeps the channel-padded K
+  static const bool dense_on = !(getenv("SE_RTILE_DENSE") && atoi(getenv("SE_RTILE_DENSE")) == 0);
+  if (dense_on && !bf && L.d_wd && L.dense && d.k == 5 && !d.up && L.cfg == GC_N48 && (long long)B * Hin * Win * C0 * 4 < (1ll << 31)) {
+    RTileParams p;
+    memset(&p, 0, sizeof p);
+    p.src = src0; p.wpk = L.d_wd; p.bias = L.d_b; p.dst = dst;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.C = C0; p.G = L.G; p.OH = Ho; p.OW = Wo;
+    p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
+    p.act = d.act; p.xcd = xcd_remap_enabled(); p.dense = L.dense; p.nch = L.nchd; p.NP = 48;
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 25;
+    set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
+                    2.0 * (double)B * Hin * Win * 48.0 * (L.nchd * 32.0));
+    HIPCHK(c, launch_rtile(p, c->st));
+    *done = true;
+    return 0;
+  }
   const int KW = d.up ? 2 : d.k, KH = KW;
   RTileParams p;
   memset(&p, 0, sizeof p);
@@ -1338,6 +1380,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_w16) (void)hipFree(kv.second.d_w16);
       if (kv.second.d_w16s) (void)hipFree(kv.second.d_w16s);
       if (kv.second.d_w96) (void)hipFree(kv.second.d_w96);
+      if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
@@ -1674,6 +1717,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   } else if (!rc) {
     if (Cout % 8) rc = fail(c, "gated conv needs Cout %% 8 == 0");
     if (!rc) rc = pack_layer(c, L, identity_map(CinT));
+    if (!rc && !bf && k == 5 && stride == 1 && rate == 1 && Cout == 48 && !Cin1 && !upsample && (Cin == 5 || Cin == 3)) rc = pack_layer_dense(c, L);
     if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
     if (!rc && bf && k == 3 && stride == 1 && !upsample && CinT == 96 && Cout == 192 && !Cin1) rc = pack_rconv16(c, L);
     if (!rc && bf && !Cin1 && rconv96_eligible(L.def)) rc = pack_rconv96(c, L);
@@ -1697,6 +1741,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_w16) (void)hipFree(L.d_w16);
   if (L.d_w16s) (void)hipFree(L.d_w16s);
   if (L.d_w96) (void)hipFree(L.d_w96);
+  if (L.d_wd) (void)hipFree(L.d_wd);
   return rc;
 }
 

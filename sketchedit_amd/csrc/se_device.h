@@ -64,6 +64,19 @@ DEVFN void bufdma16(unsigned voff, se_i32x4 rsrc, unsigned lds_addr) {
       : "v"(voff), "s"(rsrc), "s"(lds_addr)
       : "memory");
 }
+// one dword per lane: lane i writes 4 B at lds_addr + 4*i (used where a 16-byte piece would straddle a pixel boundary)
+DEVFN void bufdma4(unsigned voff, se_i32x4 rsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dword %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
 DEVFN void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 DEVFN unsigned lds_addr_of(const void* p) {

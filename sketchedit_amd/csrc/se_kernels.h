@@ -174,6 +174,8 @@ struct RTileParams {
   int div_cg_l, div_rw_l;
   int ty, tx;          // 8 x 16 tiles per image
   int act, bf16, xcd;
+  int dense;           // > 0: dense-K form of the 5x5 first layers (fp32): `dense` = real input channels (3 or 5) out of the C
+                       // stored per pixel; wpk is then the image of pack_layer_dense (k = tap * dense + channel, no channel padding)
 };
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st);
 int rtile_rows(bool bf16);    // output rows per workgroup tile (8 fp32, 32 bf16)

@@ -150,6 +150,138 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense-K form of the 5x5 first layers whose inputs carry padding channels (fp32): conv1 of netG reads 5 real channels
+// stored as NHWC8 (K = 25 taps x 8 = 200 -> 7 chunks of 32, 125 of them real), xconv1 / pmconv1 read 3 real channels
+// stored as NHWC4 (K = 100 -> 4 chunks, 75 real).  These layers are bound by the fp32 MFMA pipe, so the padding is paid
+// for in full.  Here the raw tile is staged DENSE -- [row][column][CD real channels], one dword per DMA lane, so a pixel
+// outside the image is still exactly a set of out-of-range lanes (hardware zero fill) -- and k = tap * CD + channel
+// has no channel padding at all: 125 -> 4 chunks, 75 -> 3 chunks.  A k-granule (4 consecutive k) is then no longer 16
+// contiguous bytes of one pixel: its four elements are read with four ds_read_b32 whose tile offsets come from a table
+// (built once per workgroup, one entry per k) -- two 16-byte table reads and eight address adds per chunk, against the
+// 48 MFMAs of 32 cycles a chunk is.  Same weights, row order, MFMA sequence and epilogue as rtile_kernel; the summation
+// order over k differs (channel padding removed), i.e. fp32 rounding only.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CD>
+__global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams p) {
+  constexpr int NT = 3, PT = 2, TR = 8, KW = 5, T = 25;
+  constexpr int RH = TR + KW - 1, RW = 16 + KW - 1;       // 12 x 20 source pixels
+  constexpr int ROWB = RW * CD * 4;                        // bytes per dense tile row
+  constexpr int NDW = RH * RW * CD;                        // dwords of the dense tile
+  constexpr int K = T * CD, NCH = (K + 31) / 32;
+  constexpr int RAWB = (NDW * 4 + 1023) & ~1023;
+  constexpr int TABB = NCH * 32 * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Raw = smem;
+  int* Tab = (int*)(smem + RAWB);
+  char* Wres = smem + RAWB + TABB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
+  const int ty0 = (t2 / p.tx) * TR, tx0 = (t2 % p.tx) * 16;
+  const int pixb = p.C * 4;                                // bytes per stored source pixel (padding channels included)
+
+  const unsigned lds_raw = lds_addr_of(Raw), lds_w = lds_addr_of(Wres);
+  {
+    const int npieces = NCH * 48 / 8;                      // 1 KB pieces (8 rows of 128 bytes)
+    for (int i = w; i < npieces; i += 4) glds16_s(p.wpk + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
+    const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.Hin * p.Win * (unsigned)pixb);
+    for (int i = w; i * 64 < NDW; i += 4) {
+      const int q = i * 64 + lane;
+      const int pix = q / CD, ch = q - pix * CD;           // compile-time divisors
+      const int row = pix / RW, col = pix - row * RW;
+      const int sy = ty0 - 2 + row, sx = tx0 - 2 + col;
+      const bool ok = q < NDW && (unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win;
+      const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)ch * 4u;
+      bufdma4(ok ? off : 0x80000000u, rsrc, lds_raw + i * 256);
+    }
+    // k -> byte offset of (tap, channel) inside the dense tile; k >= K (chunk padding, zero weights): any valid offset
+    if (tid < NCH * 32) {
+      const int kf = tid < K ? tid : K - 1;
+      const int tap = kf / CD, ch = kf - tap * CD, ky = tap / KW, kx = tap - ky * KW;
+      Tab[tid] = ky * ROWB + (kx * CD + ch) * 4;
+    }
+  }
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const int jx = lane & 15, g4 = lane >> 4;
+  const int xbase = ((PT * w) * RW + jx) * CD * 4;          // this lane's pixel of the wave's first row
+
+  f32x4 acc[NT][PT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_wait_all();
+  __syncthreads();
+
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    f32x4 wq[2 * NT], xb[2][PT];
+#pragma unroll
+    for (int u = 0; u < 2 * NT; ++u)
+      wq[u] = *(const f32x4*)(Wres + ch * (48 * 128) + (u % NT) * 2048 + (u / NT ? off1 : off0));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const i32x4 to = *(const i32x4*)(Tab + ch * 32 + half * 16 + g4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const char* src = Raw + xbase + to[e];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xb[half][pt][e] = *(const float*)(src + pt * ROWB);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * NT; ++u) {
+      const int half = u / NT, nt = u % NT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][r], xb[half][pt][r], acc[nt][pt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: rtile_kernel's (MIXED rows, two v_permlane32_swap per quad)
+  const int q = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
+    const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int yy = ty0 + PT * w + pt, xx = tx0 + jx;
+      const f32x4 v = acc[nt][pt] + bq;
+      const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+      const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+      const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+      float2 o;
+      o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
+      o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+      if (c0 < p.G && yy < p.Hin && xx < p.Win)
+        *(float2*)(p.dst + ((size_t)(b * p.Hin + yy) * p.Win + xx) * p.G + c0) = o;
+    }
+  }
+}
+
+template <int CD>
+static hipError_t launch_rtile_dense5(const RTileParams& p, hipStream_t st) {
+  constexpr int NDW = 12 * 20 * CD, K = 25 * CD, NCH = (K + 31) / 32;
+  constexpr int LDS = ((NDW * 4 + 1023) & ~1023) + NCH * 32 * 4 + NCH * 48 * 128;
+  hipError_t e = ensure_max_lds((const void*)rtile_dense5_kernel<CD>, 80 * 1024);
+  if (e != hipSuccess) return e;
+  const int tiles = p.B * p.ty * p.tx;
+  set_launch_grid(tiles);
+  ProfScope ps_(st, PL_GCONV_N48);
+  hipLaunchKernelGGL((rtile_dense5_kernel<CD>), dim3(tiles), dim3(256), LDS, st, p);
+  return hipGetLastError();
+}
+
 template <int NT, int PT, bool BF16>
 static hipError_t launch_rtile_t(const RTileParams& p, hipStream_t st, int label) {
   const int lds = p.raw_bytes + p.nch * p.NP * 128;
@@ -171,6 +303,9 @@ static hipError_t launch_rtile_t(const RTileParams& p, hipStream_t st, int label
 int rtile_rows(bool bf16) { return bf16 ? 32 : 8; }
 
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st) {
+  if (p.dense == 3) return launch_rtile_dense5<3>(p, st);
+  if (p.dense == 5) return launch_rtile_dense5<5>(p, st);
+  if (p.dense) return hipErrorInvalidValue;
   if (p.NP == 48) return p.bf16 ? launch_rtile_t<3, 8, true>(p, st, PL_GCONV_N48) : launch_rtile_t<3, 2, false>(p, st, PL_GCONV_N48);
   if (p.NP == 32) return p.bf16 ? launch_rtile_t<2, 8, true>(p, st, PL_GCONV_N24) : launch_rtile_t<2, 2, false>(p, st, PL_GCONV_N24);
   return hipErrorInvalidValue;

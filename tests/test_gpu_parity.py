@@ -205,6 +205,27 @@ def test_op_low_latency_shapes_vs_oracle(eng, shape):
     assert _md(y, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("case", [(5, 22, 18), (3, 22, 18), (5, 8, 16), (3, 40, 33), (5, 9, 70)], ids=lambda c: "c%d-%dx%d" % c)
+def test_op_first_layer_dense_k_vs_oracle(eng, case, monkeypatch):
+    """The 5x5 first layers whose stored input carries padding channels (5 of NHWC8, 3 of NHWC4) in the dense-K raw-tile form
+    (se_rtile.hip rtile_dense5_kernel: k = tap * cin + channel, dword-granular staging): exact, ragged and single-tile
+    sizes, image borders on every side; against the oracle and against the channel-padded form (SE_RTILE_DENSE=0)."""
+    from oracle import sketchedit_oracle as O
+    cin, H, W = case
+    a = 1.5 / np.sqrt(cin * 25)
+    w = synth.uniform(47, "d5.w%s" % (case,), (48, cin, 5, 5), -a, a)
+    b = synth.uniform(47, "d5.b%s" % (case,), (48,), -0.3, 0.3)
+    x = synth.uniform(47, "d5.x%s" % (case,), (3, cin, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu")
+    assert _md(y, ref) < TOL_OP
+    monkeypatch.setenv("SE_RTILE_DENSE", "0")
+    # (the switch is read once per process: this second call documents the A/B knob; it equals the first within rounding
+    # whichever form it ran in)
+    y2 = eng.gated_conv2d(_cuda(x), w, b)
+    assert _md(y2, ref) < TOL_OP
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
 def test_op_attention_soft_scores_vs_oracle(eng, shape):
     """Small activations keep the softmax far from one-hot (10 * <q, k> of order 1), so a wrong pairing of pixels in
