@@ -279,25 +279,35 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   return 0;
 }
 
-// Dense-K image of a 5x5 first layer (se_rtile.hip rtile_dense5_kernel): k = tap * cin + channel, no channel padding;
-// rows in the MIXED order of the N=48 configuration, slot swizzle as pack_layer.
-int pack_layer_dense(se_ctx* c, Layer& L) {
+// Dense-K image of a 5x5 first layer (se_rtile.hip rtile_dense5_kernel): k = tap * Cd + channel over the Cd channels the
+// stored input really carries (cin_map[pc] = checkpoint input channel of stored channel pc), no channel padding; in the
+// last chunk the real k are packed instruction-major (k-step (half, r) holds the four k of lane groups 0..3), so the
+// kernel issues exactly ceil(K / 4) MFMA k-steps.  Rows in the MIXED order of the N=48 configuration, slot swizzle as
+// pack_layer.
+int pack_layer_dense(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   const LayerDef& d = L.def;
-  const int G = d.cout / 2, NP = 48, T = d.k * d.k, K = T * d.cin, nch = (K + 31) / 32;
+  const int Cd = (int)cin_map.size();
+  const int G = d.cout / 2, NP = 48, T = d.k * d.k, K = T * Cd, nch = (K + 31) / 32;
   std::vector<float> img((size_t)nch * NP * 32, 0.f);
   for (int n = 0; n < NP; ++n) {
     const int oc = out_channel_of_row(GC_N48, n, G, d.cout);
     if (oc < 0) continue;
     for (int kf = 0; kf < K; ++kf) {
-      const int tap = kf / d.cin, ic = kf % d.cin, ty = tap / d.k, tx = tap % d.k;
-      const int ch = kf / 32, kin = kf % 32, s_ = kin / 4, e = kin % 4, ps = s_ ^ ((n >> 1) & 7);
+      const int tap = kf / Cd, ic = cin_map[kf % Cd], ty = tap / d.k, tx = tap % d.k;
+      const int ch = kf / 32;
+      int kin = kf % 32;
+      if (ch == nch - 1) {                       // dense_kin: j-th real k of the last chunk -> k-step j / 4, lane group j % 4
+        const int j = kin, step = j / 4, g = j % 4;
+        kin = (step / 4) * 16 + g * 4 + (step % 4);
+      }
+      const int s_ = kin / 4, e = kin % 4, ps = s_ ^ ((n >> 1) & 7);
       img[((size_t)ch * NP + n) * 32 + ps * 4 + e] = L.w[(((size_t)oc * d.cin + ic) * d.k + ty) * d.k + tx];
     }
   }
   if (L.d_wd) (void)hipFree(L.d_wd);
   HIPCHK(c, hipMalloc(&L.d_wd, img.size() * 4));
   HIPCHK(c, hipMemcpy(L.d_wd, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-  L.dense = d.cin; L.nchd = nch;
+  L.dense = Cd; L.nchd = nch;
   return 0;
 }
 
@@ -659,7 +669,11 @@ int pack_net_layer(se_ctx* c, Layer& L) {
     if (rconv96_eligible(d) && pack_rconv96(c, L)) return 1;
   }
   // 5x5 first layers whose stored input has padding channels (5 of 8, 3 of 4): dense-K image beside the padded one
-  if (d.k == 5 && d.stride == 1 && d.rate == 1 && d.cout == 48 && (d.cin == 5 || d.cin == 3) && pack_layer_dense(c, L)) return 1;
+  if (d.k == 5 && d.stride == 1 && d.rate == 1 && d.cout == 48 && d.cin >= 3 && d.cin <= 5) {
+    std::vector<int> id(d.cin);
+    for (int i = 0; i < d.cin; ++i) id[i] = i;
+    if (pack_layer_dense(c, L, id)) return 1;
+  }
   std::vector<int> m;
   if (d.k == 5 && d.cin == 5) { m.assign(8, -1); for (int i = 0; i < 5; ++i) m[i] = i; }   // NHWC8 inputs
   else m = identity_map(d.cin);
@@ -670,6 +684,7 @@ int pack_net_layer(se_ctx* c, Layer& L) {
     J.def = d; J.w = L.w; J.b = L.b; J.have_w = J.have_b = true;
     const int rc = pack_layer(c, J, std::vector<int>{0, 1, 2, 4});
     if (rc) return rc;
+    if (pack_layer_dense(c, J, std::vector<int>{0, 1, 2, 4})) return 1;
   }
   return pack_layer(c, L, m);
 }
@@ -703,7 +718,7 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
     p.act = d.act; p.xcd = xcd_remap_enabled(); p.dense = L.dense; p.nch = L.nchd; p.NP = 48;
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 25;
     set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
-                    2.0 * (double)B * Hin * Win * 48.0 * (L.nchd * 32.0));
+                    2.0 * (double)B * Hin * Win * 48.0 * (4.0 * ((25 * L.dense + 3) / 4)));       // ceil(K / 4) k-steps of 4
     HIPCHK(c, launch_rtile(p, c->st));
     *done = true;
     return 0;
@@ -1385,6 +1400,7 @@ void se_destroy(se_ctx* c) {
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
   if (c->wconv1_j4.d_w16) (void)hipFree(c->wconv1_j4.d_w16);
+  if (c->wconv1_j4.d_wd) (void)hipFree(c->wconv1_j4.d_wd);
   if (c->zeros) (void)hipFree(c->zeros);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
   drop_graphs(c);
@@ -1717,7 +1733,11 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   } else if (!rc) {
     if (Cout % 8) rc = fail(c, "gated conv needs Cout %% 8 == 0");
     if (!rc) rc = pack_layer(c, L, identity_map(CinT));
-    if (!rc && !bf && k == 5 && stride == 1 && rate == 1 && Cout == 48 && !Cin1 && !upsample && (Cin == 5 || Cin == 3)) rc = pack_layer_dense(c, L);
+    if (!rc && !bf && k == 5 && stride == 1 && rate == 1 && Cout == 48 && !Cin1 && !upsample && Cin >= 3 && Cin <= 5) {
+      std::vector<int> id(Cin);
+      for (int i = 0; i < Cin; ++i) id[i] = i;
+      rc = pack_layer_dense(c, L, id);
+    }
     if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
     if (!rc && bf && k == 3 && stride == 1 && !upsample && CinT == 96 && Cout == 192 && !Cin1) rc = pack_rconv16(c, L);
     if (!rc && bf && !Cin1 && rconv96_eligible(L.def)) rc = pack_rconv96(c, L);

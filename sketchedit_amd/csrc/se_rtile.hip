@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
 // stored as NHWC4 (K = 100 -> 4 chunks, 75 real).  These layers are bound by the fp32 MFMA pipe, so the padding is paid
 // for in full.  Here the raw tile is staged DENSE -- [row][column][CD real channels], one dword per DMA lane, so a pixel
 // outside the image is still exactly a set of out-of-range lanes (hardware zero fill) -- and k = tap * CD + channel
-// has no channel padding at all: 125 -> 4 chunks, 75 -> 3 chunks.  A k-granule (4 consecutive k) is then no longer 16
+// has no channel padding at all: 125 -> 4 chunks, 75 -> 3 chunks; and exactly ceil(K / 4) MFMA k-steps are issued (the real k
+// of the last chunk are packed into its first k-steps): 19 instead of 24 for 3 channels, 25 instead of 32 for the 4-channel
+// layers (conv1 of netM, the 4-channel wconv1), which take this form for that reason alone.  A k-granule (4 consecutive k) is then no longer 16
 // contiguous bytes of one pixel: its four elements are read with four ds_read_b32 whose tile offsets come from a table
 // (built once per workgroup, one entry per k) -- two 16-byte table reads and eight address adds per chunk, against the
 // 48 MFMAs of 32 cycles a chunk is.  Same weights, row order, MFMA sequence and epilogue as rtile_kernel; the summation
@@ -169,6 +171,8 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
   constexpr int ROWB = RW * CD * 4;                        // bytes per dense tile row
   constexpr int NDW = RH * RW * CD;                        // dwords of the dense tile
   constexpr int K = T * CD, NCH = (K + 31) / 32;
+  constexpr int REM = K - (NCH - 1) * 32;                  // real k of the last chunk
+  constexpr int LAST_STEPS = (REM + 3) / 4;                // MFMA k-steps the last chunk needs (dense_kin packs them first)
   constexpr int RAWB = (NDW * 4 + 1023) & ~1023;
   constexpr int TABB = NCH * 32 * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,9 +201,17 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
       const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)ch * 4u;
       bufdma4(ok ? off : 0x80000000u, rsrc, lds_raw + i * 256);
     }
-    // k -> byte offset of (tap, channel) inside the dense tile; k >= K (chunk padding, zero weights): any valid offset
+    // chunk slot -> byte offset of its k's (tap, channel) inside the dense tile.  In the LAST chunk the real k are packed
+    // instruction-major (dense_kin, mirrored by pack_layer_dense), so that only ceil(REM / 4) of its 8 MFMA k-steps carry
+    // data and the others are not issued at all; unused slots (zero weights, never multiplied) get any valid offset.
     if (tid < NCH * 32) {
-      const int kf = tid < K ? tid : K - 1;
+      int kf = K - 1;
+      if (tid < (NCH - 1) * 32) kf = tid;
+      else {
+        const int kin = tid - (NCH - 1) * 32, half = kin >> 4, g = (kin >> 2) & 3, r = kin & 3;
+        const int j = (half * 4 + r) * 4 + g;               // inverse of dense_kin
+        if (j < REM) kf = (NCH - 1) * 32 + j;
+      }
       const int tap = kf / CD, ch = kf - tap * CD, ky = tap / KW, kx = tap - ky * KW;
       Tab[tid] = ky * ROWB + (kx * CD + ch) * 4;
     }
@@ -239,10 +251,12 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
     for (int u = 0; u < 2 * NT; ++u) {
       const int half = u / NT, nt = u % NT;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        if (ch == NCH - 1 && half * 4 + r >= LAST_STEPS) continue;      // compile-time: k-steps of pure chunk padding
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
           acc[nt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][r], xb[half][pt][r], acc[nt][pt], 0, 0, 0);
+      }
     }
   }
 
@@ -304,6 +318,7 @@ int rtile_rows(bool bf16) { return bf16 ? 32 : 8; }
 
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st) {
   if (p.dense == 3) return launch_rtile_dense5<3>(p, st);
+  if (p.dense == 4) return launch_rtile_dense5<4>(p, st);
   if (p.dense == 5) return launch_rtile_dense5<5>(p, st);
   if (p.dense) return hipErrorInvalidValue;
   if (p.NP == 48) return p.bf16 ? launch_rtile_t<3, 8, true>(p, st, PL_GCONV_N48) : launch_rtile_t<3, 2, false>(p, st, PL_GCONV_N48);

@@ -205,7 +205,7 @@ def test_op_low_latency_shapes_vs_oracle(eng, shape):
     assert _md(y, ref) < TOL_OP
 
 
-@pytest.mark.parametrize("case", [(5, 22, 18), (3, 22, 18), (5, 8, 16), (3, 40, 33), (5, 9, 70)], ids=lambda c: "c%d-%dx%d" % c)
+@pytest.mark.parametrize("case", [(5, 22, 18), (3, 22, 18), (4, 22, 18), (5, 8, 16), (3, 40, 33), (4, 16, 48), (5, 9, 70)], ids=lambda c: "c%d-%dx%d" % c)
 def test_op_first_layer_dense_k_vs_oracle(eng, case, monkeypatch):
     """The 5x5 first layers whose stored input carries padding channels (5 of NHWC8, 3 of NHWC4) in the dense-K raw-tile form
     (se_rtile.hip rtile_dense5_kernel: k = tap * cin + channel, dword-granular staging): exact, ragged and single-tile
