@@ -4,7 +4,7 @@
 #   <cfg>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / avg duration)
 #   <cfg>_pmc_summary.txt     three separate --pmc passes (SQ busy counters, FETCH_SIZE, WRITE_SIZE), tools/pmc_summary.py
 # Everything lands under gpurun_out/<tag>/; copy into profiles/ afterwards.   usage: tools/profile_round.sh <tag> [cfg ...]
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 cfgs=${@:-"c2 c3 c5 b1"}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
