@@ -123,31 +123,43 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   }
 
   // ---- epilogue (gconv_kernel, MIXED): tile rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32); two
-  // v_permlane32_swap per quad hand every lane two complete (feature, gate) pairs
+  // v_permlane32_swap per quad hand every lane two complete (feature, gate) pairs.
+  // In bf16 this epilogue -- 24 (row tile, pixel row) pairs per lane, two gated values each -- is as long as the wave's
+  // whole MFMA loop, so it carries nothing that is not arithmetic: the activation switch is hoisted out of the loops
+  // (one instantiation per activation), the store address is one 32-bit lane offset plus compile-time / wave-uniform
+  // increments from a wave-uniform base, and the row / column / channel bounds are one lane mask and one scalar test.
   const int q = lane >> 4;
+  const int lanec = (q & 1) * 4 + (q >> 1) * 2;                      // this lane's channel pair inside a row tile
+  const int yw = ty0 + PT * w;                                       // first pixel row of this wave
+  const int rowst = (p.up2 ? 2 : 1) * p.OW * p.G * ES;               // bytes between two pixel rows of this wave (uniform)
+  char* dbase = (char*)p.dst + ((size_t)(b * p.OH + (p.up2 ? 2 * yw + py : yw)) * p.OW + (p.up2 ? 2 * tx0 + px : tx0)) * p.G * ES;
+  const unsigned voff0 = (unsigned)(((p.up2 ? 2 * jx : jx) * p.G + lanec) * ES);
+  const bool okx = tx0 + jx < p.Win;
+  auto epilogue = [&](auto elu_tag) {
+    constexpr bool ELU = decltype(elu_tag)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
-    const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
+      const bool okc = okx && nt * 8 + lanec < p.G;
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int yy = ty0 + PT * w + pt, xx = tx0 + jx;
-      const f32x4 v = acc[nt][pt] + bq;
-      const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
-      const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
-      const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
-      const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
-      float2 o;
-      o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
-      o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
-      if (c0 < p.G && yy < p.Hin && xx < p.Win) {
-        const int oy = p.up2 ? 2 * yy + py : yy, ox = p.up2 ? 2 * xx + px : xx;
-        const size_t at = ((size_t)(b * p.OH + oy) * p.OW + ox) * p.G + c0;
-        if (BF16) *(unsigned*)((char*)p.dst + at * 2) = pack_bf16x2(o.x, o.y);
-        else *(float2*)(p.dst + at) = o;
+      for (int pt = 0; pt < PT; ++pt) {
+        const f32x4 v = acc[nt][pt] + bq;
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+        const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+        const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+        float2 o;
+        o.x = (ELU ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
+        o.y = (ELU ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+        if (yw + pt < p.Hin && okc) {                                   // (row test wave-uniform)
+          char* at = dbase + (size_t)pt * rowst + (voff0 + (unsigned)(nt * 8 * ES));
+          if (BF16) *(unsigned*)at = pack_bf16x2(o.x, o.y);
+          else *(float2*)at = o;
+        }
       }
     }
-  }
+  };
+  if (p.act == 0) epilogue(std::true_type()); else epilogue(std::false_type());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
