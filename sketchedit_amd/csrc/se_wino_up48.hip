@@ -10,15 +10,16 @@
 // gather / raw-tile form, 87.0 in reference-defined FLOPs.
 // What differs from both: 48 packed rows = 3 MIXED row tiles, so there is no row split across waves -- one workgroup =
 // 4 waves = 64 tiles, a wave owns all 3 row tiles x 16 tiles (12 + 48 accumulator registers); every thread still stages
-// one tile row (two granules per iteration), i.e. the staging work per MFMA is twice that of se_wino_up.hip.  54 KB of
-// LDS: two workgroups per CU.
+// one tile row (two granules per iteration), i.e. the staging work per MFMA is twice that of se_wino_up.hip.  49.5 KB of
+// LDS and 154 VGPRs: three workgroups per CU (the third hides the staging stalls of the other two: a wave of this kernel
+// has an MFMA to issue only ~30 % of the time).
 #include "se_device.h"
 
 #include <cstdlib>
 
 namespace se {
 
-__global__ __launch_bounds__(256, 2) void winoup48_kernel(const WinoParams p) {
+__global__ __launch_bounds__(256, 3) void winoup48_kernel(const WinoParams p) {
   constexpr int TILES = 64, NTHR = 256, NWV = 4;
   constexpr int XB = TILES * 128, WB = 48 * 128;
   constexpr int NIT = 14;              // 4 position pairs x 3 chunks + chunks A, B of the pair (8, -)
@@ -51,22 +52,26 @@ __global__ __launch_bounds__(256, 2) void winoup48_kernel(const WinoParams p) {
   const int swz = (srow >> 1) & 7;
   char* xw0 = Xb + srow * 128 + ((sg ^ swz) << 4);             // k-half 0: logical slot sg
   char* xw1 = Xb + srow * 128 + (((4 + sg) ^ swz) << 4);       // k-half 1: logical slot 4 + sg
-  // Source offsets of the 3x3 input tile, kept in LDS (read once per position):
-  //   Ysrc[i][tid] = byte offset of source row yy0 - 1 + py + i (+ this lane's granule), or -1 if outside / invalid tile
-  //   Xsrc[i][tid] = byte offset of source column xx0 - 1 + px + i inside the row, or -1 if outside
+  // Source offsets of the 3x3 input tile, kept in LDS (read once per position), one entry per TILE (the four lanes that
+  // stage a tile's four granules read the same entry and add their granule offset): 1.5 KB instead of 6 KB, which is what
+  // brings the workgroup under a third of the CU's LDS -- three workgroups per CU instead of two (round 3; 154 VGPRs).
+  //   Ysrc[i][tile] = byte offset of source row yy0 - 1 + py + i, or -1 if outside / invalid tile
+  //   Xsrc[i][tile] = byte offset of source column xx0 - 1 + px + i inside the row, or -1 if outside
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
-  int* Xsrc = Ysrc + 3 * NTHR;
-  {
-    const int t = tile_base + srow;
+  int* Xsrc = Ysrc + 3 * TILES;
+  if (tid < TILES) {
+    const int t = tile_base + tid;
     int b, y0, x0;
     tile_origin(t < p.total_tiles ? t : 0, b, y0, x0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int y = y0 - 1 + py + i, x = x0 - 1 + px + i;
-      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : -1;
-      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
+      Ysrc[i * TILES + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u) : -1;
+      Xsrc[i * TILES + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
     }
   }
+  __syncthreads();
+  const unsigned sg16 = (unsigned)sg * 16u;
   const unsigned lds_w = lds_addr_of(Wb);
   int off0, off1;
   frag_offsets(lane, off0, off1);
@@ -83,12 +88,12 @@ __global__ __launch_bounds__(256, 2) void winoup48_kernel(const WinoParams p) {
   auto set_pos = [&](int set, int pos) {    // compile-time arguments after unrolling
     const int pc = pos < NPOS ? pos : NPOS - 1;
     const int xi = pc / 3, nu = pc % 3;
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = Ysrc[(xi == 2 ? 2 : 1) * NTHR + tid];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = Xsrc[(nu == 2 ? 2 : 1) * NTHR + tid];
+    const int ya = Ysrc[(xi == 0 ? 0 : 1) * TILES + srow], yb = Ysrc[(xi == 2 ? 2 : 1) * TILES + srow];
+    const int xa = Xsrc[(nu == 0 ? 0 : 1) * TILES + srow], xb = Xsrc[(nu == 2 ? 2 : 1) * TILES + srow];
     const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = (xi == 1 || yb < 0) ? 0.f : (xi == 0 ? -1.f : 1.f);
     const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = (nu == 1 || xb < 0) ? 0.f : (nu == 0 ? -1.f : 1.f);
     // always load from a valid (clamped) address; the padding zero is applied through the factor
-    const unsigned ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
+    const unsigned ya_c = max(ya, 0) + sg16, yb_c = max(yb, 0) + sg16, xa_c = max(xa, 0), xb_c = max(xb, 0);
     o[set][0] = ya_c + xa_c; o[set][1] = ya_c + xb_c; o[set][2] = yb_c + xa_c; o[set][3] = yb_c + xb_c;
     g[set][0] = sxa * sya; g[set][1] = sxb * sya; g[set][2] = sxa * syb; g[set][3] = sxb * syb;
   };
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void winoup48_kernel(const WinoParams p) {
 
 hipError_t launch_winoup48(const WinoParams& p, hipStream_t st) {
   constexpr int TILES = 64;
-  constexpr int LDS = 3 * TILES * 128 + 4 * 48 * 128 + 6 * TILES * 4 * 4;     // X ring 24 KB + W ring 24 KB + source offsets 6 KB
+  constexpr int LDS = 3 * TILES * 128 + 4 * 48 * 128 + 6 * TILES * 4;     // X ring 24 KB + W ring 24 KB + source offsets 1.5 KB: three per CU
   {
     hipError_t e = ensure_max_lds((const void*)winoup48_kernel, LDS);
     if (e != hipSuccess) return e;
