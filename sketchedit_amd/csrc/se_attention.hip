@@ -1001,36 +1001,44 @@ __global__ __launch_bounds__(256) void att2_ptilde1_kernel(const AttParams p) {
   }
 }
 
-// out[b, 2r + cls, c] = sum_s P~[r][s] * xT[cls][c][s]: A tile = 96 channel rows x 32 keys, MFMA columns = class-grid pixels
-template <int PT, bool BF16>
+// out[b, 2r + cls, c] = sum_s P~[r][s] * xT[cls][c][s]: A tile = NT * 16 channel rows x 32 keys, MFMA columns = class-grid pixels.
+// <PT = 4, NT = 6>: 256 pixels x all 96 channels per workgroup (large batches).  <PT = 1, NT = 3>: 64 pixels x one half of
+// the channels -- 8x the workgroups for calls whose grid would otherwise leave most of the 256 CUs idle (one 256x256
+// image: 16 workgroups -> 128; the k order of every output is the same, so the results are bit-identical).
+template <int PT, int NT, bool BF16>
 __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
-  constexpr int NT = 6, PIX = PT * 64, NP = 96;
+  constexpr int PIX = PT * 64, NP = NT * 16, NRH = 6 / NT;      // row halves per (pixel tile, class)
   constexpr int ES = BF16 ? 2 : 4;
   constexpr int XBYTES = PIX * 128, WBYTES = NP * 128;
-  constexpr int NX = PT * 2, NW = 3;
+  constexpr int NX = PT * 2, NW = (NT * 2 + 3) / 4;      // 8-row blocks of the two tiles staged per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;                        // P~ tiles [PIX][32 keys]
-  char* Wb = smem + 2 * XBYTES;           // V^T tiles [96 ch][32 keys]
+  char* Wb = smem + 2 * XBYTES;           // V^T tiles [NP ch][32 keys]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // 1-D grid in (image, pixel tile, class) order, class fastest, every XCD a contiguous range (xcd_tile): the four
+  // 1-D grid in (image, pixel tile, row half, class) order, class fastest, every XCD a contiguous range (xcd_tile): the
   // class workgroups of a pixel tile run side by side on one XCD and share the P~ tile through its L2
   const int lb = xcd_tile(blockIdx.x, gridDim.x);
   const int cls = lb & 3, py = cls >> 1, px = cls & 1;
+  const int rh = (lb >> 2) % NRH, lt = (lb >> 2) / NRH;
   const int nt_ = (p.R + PIX - 1) / PIX;
-  const int b = (lb >> 2) / nt_, t0 = ((lb >> 2) - b * nt_) * PIX;
+  const int b = lt / nt_, t0 = (lt - b * nt_) * PIX;
   const int s_log = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
   const se_i32x4 rs_P = make_rsrc((const char*)p.Pt + (size_t)b * p.R * p.Rp * ES, (unsigned)p.R * p.Rp * (unsigned)ES);
-  const se_i32x4 rs_V = make_rsrc((const char*)p.xT + ((size_t)b * 4 + cls) * 96 * p.Rp * ES, 96u * p.Rp * (unsigned)ES);
+  const se_i32x4 rs_V = make_rsrc((const char*)p.xT + (((size_t)b * 4 + cls) * 96 + rh * NP) * p.Rp * ES, (unsigned)NP * p.Rp * (unsigned)ES);
   unsigned xo[NX], wo[NW];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int r = t0 + (i * 4 + w) * 8 + (lane >> 3);
-    xo[i] = r < p.R ? (unsigned)(r * p.Rp) * (unsigned)ES + s_log * 16u : 0x80000000u;
+    const int rl = (i * 4 + w) * 8 + (lane >> 3);                // row of the tile staged by this lane
+    const int r = t0 + rl;
+    xo[i] = (rl < PIX && r < p.R) ? (unsigned)(r * p.Rp) * (unsigned)ES + s_log * 16u : 0x80000000u;
   }
 #pragma unroll
-  for (int j = 0; j < NW; ++j) wo[j] = (unsigned)(((j * 4 + w) * 8 + (lane >> 3)) * p.Rp) * (unsigned)ES + s_log * 16u;
+  for (int j = 0; j < NW; ++j) {
+    const int rl = (j * 4 + w) * 8 + (lane >> 3);
+    wo[j] = rl < NP ? (unsigned)(rl * p.Rp) * (unsigned)ES + s_log * 16u : 0x80000000u;
+  }
   int off0, off1;
   frag_offsets(lane, off0, off1);
   const unsigned lds_x = lds_addr_of(Xb), lds_w = lds_addr_of(Wb);
@@ -1039,9 +1047,11 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
   auto stage = [&](int ch, int buf) {
     const unsigned delta = (unsigned)ch * 128u;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) bufdma16(xo[i] + delta, rs_P, lds_x + buf * XBYTES + (i * 4 + w) * 1024);
+    for (int i = 0; i < NX; ++i)
+      if ((i * 4 + w) * 8 < PIX) bufdma16(xo[i] + delta, rs_P, lds_x + buf * XBYTES + (i * 4 + w) * 1024);
 #pragma unroll
-    for (int j = 0; j < NW; ++j) bufdma16(wo[j] + delta, rs_V, lds_w + buf * WBYTES + (j * 4 + w) * 1024);
+    for (int j = 0; j < NW; ++j)
+      if ((j * 4 + w) * 8 < NP) bufdma16(wo[j] + delta, rs_V, lds_w + buf * WBYTES + (j * 4 + w) * 1024);
   };
 
   f32x4 acc[NT][PT];
@@ -1067,7 +1077,7 @@ __global__ __launch_bounds__(256) void att2_pv_kernel(const AttParams p) {
     const int i = t0 + (w * PT + pt) * 16 + (lane & 15);
     if (i >= p.R) continue;
     const int yy = i / p.wc, xx = i - yy * p.wc;
-    char* o = (char*)p.out + ((long)(b * p.h + 2 * yy + py) * p.w + 2 * xx + px) * 96 * ES;
+    char* o = (char*)p.out + (((long)(b * p.h + 2 * yy + py) * p.w + 2 * xx + px) * 96 + rh * NP) * ES;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 a = acc[nt][pt];
@@ -1120,16 +1130,28 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     hipLaunchKernelGGL(att2_transpose_kernel<BF16>, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);
   }
   {
-    constexpr int NT = 4, PT = 4;
-    constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
-    hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
-    if (e != hipSuccess) return e;
-    dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * (double)p.R * p.R * 384.0);
-    set_launch_grid((long)grid.x * grid.y * grid.z);
-    ProfScope ps_(st, PL_ATT_SCORE);
-    hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
+    const long big_grid = (long)((p.R + 255) / 256) * ((p.R + 63) / 64) * p.B;
+    if (big_grid >= 512) {
+      constexpr int NT = 4, PT = 4;
+      constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+      hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
+      if (e != hipSuccess) return e;
+      dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+      set_launch_grid((long)grid.x * grid.y * grid.z);
+      ProfScope ps_(st, PL_ATT_SCORE);
+      hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
+    } else {          // one or a few small images: 128 queries x 32 keys per workgroup, 4x the workgroups (same k order: same bits)
+      constexpr int NT = 2, PT = 2;
+      constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+      hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
+      if (e != hipSuccess) return e;
+      dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+      set_launch_grid((long)grid.x * grid.y * grid.z);
+      ProfScope ps_(st, PL_ATT_SCORE);
+      hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
+    }
   }
   if (fused) {
     {
@@ -1169,16 +1191,29 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     }
   }
   {
-    constexpr int PT = 4;
-    constexpr int LDS = 2 * PT * 64 * 128 + 2 * 96 * 128;
-    hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, BF16>, LDS);
-    if (e != hipSuccess) return e;
-    dim3 grid(((p.R + PT * 64 - 1) / (PT * 64)) * 4 * p.B);
+    // small calls (one or a few images): 64-pixel tiles x half the channels, 8x the workgroups (att2_pv_kernel)
+    const long big_grid = (long)((p.R + 255) / 256) * 4 * p.B;
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * 4.0 * (double)p.R * p.Rp * 96.0);
-    set_launch_grid((long)grid.x * grid.y * grid.z);
-    ProfScope ps_(st, PL_ATT_PV);
-    hipLaunchKernelGGL((att2_pv_kernel<PT, BF16>), grid, dim3(256), LDS, st, p);
+    if (big_grid >= 512) {
+      constexpr int PT = 4, NT = 6;
+      constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+      hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, NT, BF16>, LDS);
+      if (e != hipSuccess) return e;
+      dim3 grid((unsigned)big_grid);
+      set_launch_grid((long)grid.x);
+      ProfScope ps_(st, PL_ATT_PV);
+      hipLaunchKernelGGL((att2_pv_kernel<PT, NT, BF16>), grid, dim3(256), LDS, st, p);
+    } else {
+      constexpr int PT = 1, NT = 3;
+      constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+      hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, NT, BF16>, LDS);
+      if (e != hipSuccess) return e;
+      dim3 grid((unsigned)(((p.R + 63) / 64) * 2 * 4 * p.B));
+      set_launch_grid((long)grid.x);
+      ProfScope ps_(st, PL_ATT_PV);
+      hipLaunchKernelGGL((att2_pv_kernel<PT, NT, BF16>), grid, dim3(256), LDS, st, p);
+    }
   }
   return hipGetLastError();
 }

@@ -81,9 +81,10 @@ ProfScope::~ProfScope() {
 //     the end) -- half the VALU issue slots;
 //   * blocks are handed to the XCDs in contiguous ranges (xcd_tile), so the two halo rows a strip shares with its
 //     vertical neighbours come out of the same L2.
-template <int COUT, bool BF16>
+// SR = output rows per lane (a ragged last strip is masked): 4, or 2 for calls of one or two small images, whose 4-row
+// strips would occupy only a quarter of the CUs (one 256x256 image: 64 blocks)
+template <int COUT, bool BF16, int SR>
 __global__ __launch_bounds__(256) void small_conv_kernel(const SmallConvParams p) {
-  constexpr int SR = 4;                       // output rows per lane (a ragged last strip is masked)
   const int HW = p.H * p.W;
   const int strips = (p.H + SR - 1) / SR;
   const long sidx = (long)xcd_tile(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (image, strip, column)
@@ -241,18 +242,21 @@ hipError_t launch_small_conv(const SmallConvParams& p0, hipStream_t st) {
     if (p0.composed) p.composed = p0.composed + (size_t)b0 * (p0.comp_bs ? p0.comp_bs : 3 * HW);
     if (p0.rgb8) p.rgb8 = p0.rgb8 + (size_t)b0 * HW * 3;
     if (p0.m8) p.m8 = p0.m8 + (size_t)b0 * HW;
-    const long n = (long)p.B * ((p.H + 3) / 4) * p.W;
+    const long n4 = (long)p.B * ((p.H + 3) / 4) * p.W;
+    const bool small = (n4 + 255) / 256 < 256;                       // fewer blocks than CUs: 2-row strips
+    const long n = small ? (long)p.B * ((p.H + 1) / 2) * p.W : n4;
     const int grid = (int)((n + 255) / 256);
-    if (p.cout == 1 && !p.bf16)
-      hipLaunchKernelGGL((small_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, p);
-    else if (p.cout == 3 && !p.bf16)
-      hipLaunchKernelGGL((small_conv_kernel<3, false>), dim3(grid), dim3(256), 0, st, p);
-    else if (p.cout == 1)
-      hipLaunchKernelGGL((small_conv_kernel<1, true>), dim3(grid), dim3(256), 0, st, p);
-    else if (p.cout == 3)
-      hipLaunchKernelGGL((small_conv_kernel<3, true>), dim3(grid), dim3(256), 0, st, p);
-    else
-      return hipErrorInvalidValue;
+#define SE_SC_LAUNCH(CO, BF)                                                                                        \
+    do {                                                                                                              \
+      if (small) hipLaunchKernelGGL((small_conv_kernel<CO, BF, 2>), dim3(grid), dim3(256), 0, st, p);                 \
+      else hipLaunchKernelGGL((small_conv_kernel<CO, BF, 4>), dim3(grid), dim3(256), 0, st, p);                       \
+    } while (0)
+    if (p.cout == 1 && !p.bf16) SE_SC_LAUNCH(1, false);
+    else if (p.cout == 3 && !p.bf16) SE_SC_LAUNCH(3, false);
+    else if (p.cout == 1) SE_SC_LAUNCH(1, true);
+    else if (p.cout == 3) SE_SC_LAUNCH(3, true);
+    else return hipErrorInvalidValue;
+#undef SE_SC_LAUNCH
   }
   return hipGetLastError();
 }
