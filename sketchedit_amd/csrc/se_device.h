@@ -88,8 +88,22 @@ DEVFN float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // three orders below the 1e-3 parity budget
 DEVFN float fast_exp(float x) { return __expf(x); }
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-DEVFN float elu_fast(float x) { return x > 0.f ? x : fast_exp(x) - 1.f; }
+// branch-free on purpose: written as `x > 0 ? x : exp(x) - 1`, hipcc guards the exponential with a per-VALUE branch
+// (s_cbranch_execnz: "does any lane need it?") -- 48 branches in a 48-value epilogue
+DEVFN float elu_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896340736f) - 1.f;
+  return x > 0.f ? x : e;
+}
 DEVFN float sigmoid_fast(float x) { return fast_rcp(1.f + fast_exp(-x)); }
+// ELU / ReLU of the gated epilogues without a branch or a select on the activation type: act(x) = max(x, 0) + w (e^min(x, 0) - 1)
+// with the wave-uniform weight w = 1 (ELU) or 0 (ReLU).  Exact for x >= 0 (e^0 - 1 = 0), the former elu_fast(x) for x < 0.
+// (`p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)` compiled to two scalar branches PER VALUE in the 48-value bf16 epilogues.)
+DEVFN float act_fast(float x, float eluw) {
+  const float pos = __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());       // max(x, 0) in one instruction
+  const float neg = __builtin_amdgcn_fmed3f(x, -__builtin_inff(), 0.f);      // min(x, 0)
+  const float e = __builtin_amdgcn_exp2f(neg * 1.44269504088896340736f) - 1.f;
+  return fmaf(eluw, e, pos);
+}
 // tanh(x) = 1 - 2 / (1 + e^(2x)): saturates correctly (e^(2x) -> inf gives 1, -> 0 gives -1); absolute error ~2e-7 -- ocml's
 // tanhf costs ~40 VALU instructions, a third of small_conv_kernel<3>'s multiply-add work
 DEVFN float tanh_fast(float x) { return 1.f - 2.f * fast_rcp(1.f + fast_exp(2.f * x)); }

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   int2* rowtab = (int2*)smem;   // aliases the X buffers: consumed into registers before the first DMA
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // sub-pixel upsample form: this workgroup computes output pixels (2yy+py, 2xx+px); taps (a,b) in {0,1}^2 read
   // source (yy + a - 1 + py, xx + b - 1 + px) with weights summed over the 3x3 taps that collapse onto it.  The four
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
         for (int r = 0; r < 4; ++r) {
           const float f = acc[nt][pt][r] + bf[r];
           const float g = acc[nt + NF][pt][r] + bg[r];
-          const float a = p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f);
+          const float a = act_fast(f, eluw);
           o[r] = a * sigmoid_fast(g);
         }
         if (c0 < p.G && pidx < p.total_pix) {
@@ -305,8 +306,8 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
         const float f0 = __uint_as_float(s02[0]), g0 = __uint_as_float(s02[1]);
         const float f1 = __uint_as_float(s13[0]), g1 = __uint_as_float(s13[1]);
         float2 o;
-        o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(g0);
-        o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(g1);
+        o.x = act_fast(f0, eluw) * sigmoid_fast(g0);
+        o.y = act_fast(f1, eluw) * sigmoid_fast(g1);
         if (c0 < p.G && pidx < p.total_pix) {
           if (BF16) *(unsigned*)((char*)p.dst + (out_off(pidx) + c0) * 2) = pack_bf16x2(o.x, o.y);
           else *(float2*)(p.dst + out_off(pidx) + c0) = o;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
   char* Wb = smem + RAWB;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroup -> (image, phase, tile); tiles of one sub-image are neighbours in one XCD's share of the grid
   const int lb = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void rconv16_kernel(const RConvParams p) {
       for (int r = 0; r < 4; ++r) {
         const float f = acc[nt][pt][r] + bf[r];
         const float g = acc[nt + 3][pt][r] + bg[r];
-        ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
+        ov[r] = act_fast(f, eluw) * sigmoid_fast(g);
       }
       *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
     }
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   char* Wb = smem + RAWB;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lb = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int tpi = p.ty * p.tx, per_img = p.d * p.d * tpi;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
       for (int r = 0; r < 4; ++r) {
         const float f = acc[nt][pt][r] + bf[r];
         const float g = acc[nt + 3][pt][r] + bg[r];
-        ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
+        ov[r] = act_fast(f, eluw) * sigmoid_fast(g);
       }
       *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
     }

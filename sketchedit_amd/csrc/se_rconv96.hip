@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
   char* Wb = smem + RAWB;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = p.B * p.ty * p.tx;
   int tile, cls = 0;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
       for (int r = 0; r < 4; ++r) {
         const float f = acc[nt][pt][r] + bf[r];
         const float g = acc[nt + 3][pt][r] + bg[r];
-        ov[r] = (p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)) * sigmoid_fast(g);
+        ov[r] = act_fast(f, eluw) * sigmoid_fast(g);
       }
       *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
     }

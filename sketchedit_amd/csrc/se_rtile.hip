@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   char* Wres = smem + p.raw_bytes;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = p.B * p.ty * p.tx;
   int tile, cls = 0;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
   char* Wres = smem + RAWB + TABB;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
       const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
       const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
       float2 o;
-      o.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
-      o.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+      o.x = act_fast(f0, eluw) * sigmoid_fast(gg0);
+      o.y = act_fast(f1, eluw) * sigmoid_fast(gg1);
       if (c0 < p.G && yy < p.Hin && xx < p.Win)
         *(float2*)(p.dst + ((size_t)(b * p.Hin + yy) * p.Win + xx) * p.G + c0) = o;
     }

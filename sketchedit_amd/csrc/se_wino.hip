@@ -87,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   char* Wb = smem + 3 * XB;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chh = w & 1, tg = w >> 1;          // channel half, tile group
   const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
           for (int e = 0; e < 4; ++e) {
             const float f = of[a][bb][j][e] + bf[e];
             const float g = og[a][bb][j][e] + bg[e];
-            const float act = p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f);
+            const float act = act_fast(f, eluw);
             o[e] = act * sigmoid_fast(g);
           }
           *(f32x4*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 96 + c0) = o;

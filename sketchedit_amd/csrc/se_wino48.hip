@@ -56,6 +56,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
   char* Wb = smem + 3 * XB;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chh = w & 1, tp = w >> 1;          // row half (3 MIXED tiles = 24 channels), tile pair (32 tiles)
   const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
@@ -314,8 +315,8 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
           const float f0 = __uint_as_float(s02[0]), g0 = __uint_as_float(s02[1]);
           const float f1 = __uint_as_float(s13[0]), g1 = __uint_as_float(s13[1]);
           float2 ov;
-          ov.x = (p.act == 0 ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(g0);
-          ov.y = (p.act == 0 ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(g1);
+          ov.x = act_fast(f0, eluw) * sigmoid_fast(g0);
+          ov.y = act_fast(f1, eluw) * sigmoid_fast(g1);
           if (t < p.total_tiles)
             *(float2*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 48 + c0) = ov;
         }
