@@ -1195,12 +1195,34 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     const long big_grid = (long)((p.R + 255) / 256) * 4 * p.B;
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
                     2.0 * p.B * 4.0 * (double)p.R * p.Rp * 96.0);
-    if (big_grid >= 512) {
+    // pixel tile of the large-batch form, chosen on the GPU (SE_ATT_PV_PT overrides): 256 pixels (PT = 4) need 88 KB of LDS --
+    // ONE workgroup per CU; 128 (fp32) / 192 (bf16) fit two, whose barrier and DMA waits overlap: fp32 784 -> 747 us at
+    // 512x512 B=8, bf16 307 -> 247 us at 512x512 B=16 (same box, round 3)
+    static const int pvpt = getenv("SE_ATT_PV_PT") ? atoi(getenv("SE_ATT_PV_PT")) : (BF16 ? 3 : 2);
+    if (big_grid >= 512 && pvpt == 4) {
       constexpr int PT = 4, NT = 6;
       constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
       hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, NT, BF16>, LDS);
       if (e != hipSuccess) return e;
       dim3 grid((unsigned)big_grid);
+      set_launch_grid((long)grid.x);
+      ProfScope ps_(st, PL_ATT_PV);
+      hipLaunchKernelGGL((att2_pv_kernel<PT, NT, BF16>), grid, dim3(256), LDS, st, p);
+    } else if (big_grid >= 512 && pvpt == 3) {
+      constexpr int PT = 3, NT = 6;
+      constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+      hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, NT, BF16>, LDS);
+      if (e != hipSuccess) return e;
+      dim3 grid((unsigned)(((p.R + 191) / 192) * 4 * p.B));
+      set_launch_grid((long)grid.x);
+      ProfScope ps_(st, PL_ATT_PV);
+      hipLaunchKernelGGL((att2_pv_kernel<PT, NT, BF16>), grid, dim3(256), LDS, st, p);
+    } else if (big_grid >= 512 && pvpt == 2) {
+      constexpr int PT = 2, NT = 6;
+      constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
+      hipError_t e = ensure_max_lds((const void*)att2_pv_kernel<PT, NT, BF16>, LDS);
+      if (e != hipSuccess) return e;
+      dim3 grid((unsigned)(((p.R + 127) / 128) * 4 * p.B));
       set_launch_grid((long)grid.x);
       ProfScope ps_(st, PL_ATT_PV);
       hipLaunchKernelGGL((att2_pv_kernel<PT, NT, BF16>), grid, dim3(256), LDS, st, p);
