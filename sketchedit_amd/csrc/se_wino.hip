@@ -53,7 +53,7 @@ extern "C" int se_debug_wino_trace(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_trace), sizeof(unsigned long long) * 96 * 8);
 }
 // stamps go to LDS (a global store per stamp would sit in vmcnt and distort the waits being measured)
-#define WINO_TRACE_LDS (3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4)
+#define WINO_TRACE_LDS (3 * 64 * 128 + 4 * 192 * 128 + 16 * 512 * 4)
 #define WINO_STAMP(k)                                                   \
   do {                                                                  \
     if (blockIdx.x == 0 && (w & 3) == 0) {                              \
@@ -111,6 +111,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
   int* Xsrc = Ysrc + 4 * 512;
+  // ... and, beside them, the validity of each row / column as a float (1 inside the image, 0 outside): with the offsets
+  // stored CLAMPED, set_pos is 8 LDS reads, 4 adds and 4 multiplies -- no compare, select or max (round 3: every VALU
+  // instruction of the loop is a lost fp32 MFMA slot)
+  float* Yval = (float*)(Xsrc + 4 * 512);
+  float* Xval = Yval + 4 * 512;
   const unsigned lane_coff = (unsigned)s_log * 16u;
   int bimg;             // batch index of this lane's tile (address of the per-image vector source)
   {
@@ -121,8 +126,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
-      Ysrc[i * 512 + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + lane_coff) : -1;
-      Xsrc[i * 512 + tid] = ((unsigned)x < (unsigned)p.w) ? x * 384 : -1;
+      const bool yok = t < p.total_tiles && (unsigned)y < (unsigned)p.h, xok = (unsigned)x < (unsigned)p.w;
+      Ysrc[i * 512 + tid] = (int)((unsigned)((b * p.h + (yok ? y : 0)) * p.w) * 384u + lane_coff);
+      Xsrc[i * 512 + tid] = xok ? x * 384 : 0;
+      Yval[i * 512 + tid] = yok ? 1.f : 0.f;
+      Xval[i * 512 + tid] = xok ? 1.f : 0.f;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -137,13 +145,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   float g[4];           // their B^T factors (0 for a pixel outside the image: zero padding)
   auto set_pos = [&](int xi, int nu) {      // xi uniform (loop counter), nu compile-time in the loop
     // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * 512 + tid], yb = Ysrc[(xi == 3 ? 3 : 2) * 512 + tid];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * 512 + tid], xb = Xsrc[(nu == 3 ? 3 : 2) * 512 + tid];
-    const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = yb < 0 ? 0.f : ((xi == 0 || xi == 3) ? -1.f : 1.f);
-    const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = xb < 0 ? 0.f : ((nu == 0 || nu == 3) ? -1.f : 1.f);
-    // always load from a valid (clamped) address; the padding zero is applied through the factor
-    const unsigned ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
-    o[0] = ya_c + xa_c; o[1] = ya_c + xb_c; o[2] = yb_c + xa_c; o[3] = yb_c + xb_c;
+    const int ia = (xi == 0 ? 0 : 1) * 512 + tid, ib = (xi == 3 ? 3 : 2) * 512 + tid;
+    const int ja = (nu == 0 ? 0 : 1) * 512 + tid, jb = (nu == 3 ? 3 : 2) * 512 + tid;
+    const unsigned ya = Ysrc[ia], yb = Ysrc[ib], xa = Xsrc[ja], xb = Xsrc[jb];
+    // signed validities: the B^T sign is a compile-time negation of a table value (free source modifier)
+    const float sya = xi == 2 ? -Yval[ia] : Yval[ia], syb = (xi == 0 || xi == 3) ? -Yval[ib] : Yval[ib];
+    const float sxa = nu == 2 ? -Xval[ja] : Xval[ja], sxb = (nu == 0 || nu == 3) ? -Xval[jb] : Xval[jb];
+    o[0] = ya + xa; o[1] = ya + xb; o[2] = yb + xa; o[3] = yb + xb;
     g[0] = sxa * sya; g[1] = sxb * sya; g[2] = sxa * syb; g[3] = sxb * syb;
   };
   const unsigned vec_off = (unsigned)bimg * 384u + lane_coff;     // per-image vector source (NCHK == 6 only)
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 
 template <int NCHK>
 static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 24 KB + W ring 96 KB + source offsets
+  constexpr int LDS = 3 * 64 * 128 + 4 * 192 * 128 + 16 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 24 KB + W ring 96 KB + source offsets / validities 32 KB
   {
     hipError_t e = ensure_max_lds((const void*)wino_kernel<NCHK>, LDS);
     if (e != hipSuccess) return e;
