@@ -77,6 +77,8 @@ struct Layer {
   int nch16 = 0, CGp16 = 0;
   float* d_w16s = nullptr;    // 96 -> 192 3x3 only: the 32-k step image of the 8 x 16 raw-tile kernel (se_rconv16.hip)
   float* d_w96 = nullptr;     // 96-row stride-1 layers: the 32-k step image of se_rconv96.hip
+  float* d_u1 = nullptr;      // two-source 96+96 -> 192 layers: Winograd image of the FIRST source's 96 channels alone, and
+  float* d_wv = nullptr;      //   the second source's direct weights [9 taps][96][192 packed rows] (vector source folded into a bias)
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
@@ -144,6 +146,7 @@ struct se_ctx {
   bool dry = false;
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
+  float* vbias_ws = nullptr;       // [B][9][192] scratch for the folded vector source of the next two-source layer (plan_netG)
   unsigned char* rgb8 = nullptr;   // se_inference_u8: uint8 outputs written by the last kernel of the running call
   unsigned char* m8 = nullptr;
   Profiler prof;
@@ -471,6 +474,26 @@ int pack_wino(se_ctx* c, Layer& L) {
   if (L.d_u) (void)hipFree(L.d_u);
   HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
   HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  if (d.cin == 192) {
+    // for a spatially constant second source (conv11 of netG: the pooled style vector) the layer runs as the single-source
+    // kernel on the first 96 channels plus a per-image bias table (launch_vecbias): the first source's Winograd image
+    // ([16 positions][3 chunks][192][32], the first three chunks of every position of `img`) and the second source's
+    // DIRECT weights [tap][channel][packed row]
+    std::vector<float> img1((size_t)16 * 3 * NP * 32), wv((size_t)9 * 96 * NP);
+    for (int pos = 0; pos < 16; ++pos)
+      memcpy(&img1[(size_t)pos * 3 * NP * 32], &img[(size_t)pos * nch * NP * 32], (size_t)3 * NP * 32 * 4);
+    for (int n = 0; n < NP; ++n) {
+      const int oc = out_channel_of_row(GC_N192, n, 96, 192);
+      for (int t = 0; t < 9; ++t)
+        for (int ch = 0; ch < 96; ++ch) wv[((size_t)t * 96 + ch) * NP + n] = L.w[((size_t)oc * d.cin + 96 + ch) * 9 + t];
+    }
+    if (L.d_u1) (void)hipFree(L.d_u1);
+    if (L.d_wv) (void)hipFree(L.d_wv);
+    HIPCHK(c, hipMalloc(&L.d_u1, img1.size() * 4));
+    HIPCHK(c, hipMalloc(&L.d_wv, wv.size() * 4));
+    HIPCHK(c, hipMemcpy(L.d_u1, img1.data(), img1.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(L.d_wv, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -871,6 +894,17 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.src1 = src1; wp.src1_vec = src1_vec;
     wp.upk = L.d_u; wp.bias = L.d_b; wp.dst = dst;
+    // A spatially constant second source is folded into a per-image, per-border-configuration bias (launch_vecbias) and
+    // the layer runs as the SINGLE-source kernel: half the positions' K, 311 -> 170 us at 256x256 B=32 (SE_VECBIAS=0: the
+    // two-source kernel reads the vector as a second input)
+    const char* vb_env = getenv("SE_VECBIAS");            // (read per call: the tests compare both forms in one process)
+    const bool vecbias_on = !(vb_env && atoi(vb_env) == 0);
+    bool folded = false;
+    if (vecbias_on && src1 && src1_vec && d.rate == 1 && L.d_u1 && L.d_wv && c->vbias_ws && Hin >= 2 && Win >= 2) {
+      HIPCHK(c, launch_vecbias(L.d_wv, src1, c->vbias_ws, B, 96, c->st));
+      wp.src1 = nullptr; wp.src1_vec = 0; wp.upk = L.d_u1; wp.vbias = c->vbias_ws;
+      folded = true;
+    }
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
@@ -879,7 +913,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
-    set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 16.0 / 36.0);      // F(2x2,3x3): 16 of 36 products
+    // F(2x2,3x3): 16 of 36 products; with the vector source folded away only the first source's half of K is executed
+    set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 16.0 / 36.0 * (folded ? 0.5 : 1.0));
     HIPCHK(c, launch_wino(wp, c->st));
     return 0;
   }
@@ -1167,7 +1202,12 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   Act xc = encoder(P, "conv", cin, nullptr);
   if (P.rc) return P.rc;
   if (P.join()) return 1;
+  float* vb = P.alloc_raw((size_t)B * 9 * 192);     // bias table of the folded style vector (run_gconv)
+  if (P.rc) return P.rc;
+  c->vbias_ws = c->bf16 ? nullptr : vb;
   Act d = decoder(P, "conv", xc, vec.p, 96, 1);     // :167-175 (cat is virtual)
+  c->vbias_ws = nullptr;
+  P.release(vb);
   P.free(vec);
   Act xnow = P.alloc(H, W, 4);
   if (P.rc) return P.rc;
@@ -1396,6 +1436,8 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_w16s) (void)hipFree(kv.second.d_w16s);
       if (kv.second.d_w96) (void)hipFree(kv.second.d_w96);
       if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
+      if (kv.second.d_u1) (void)hipFree(kv.second.d_u1);
+      if (kv.second.d_wv) (void)hipFree(kv.second.d_wv);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
@@ -1706,7 +1748,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   L.b.assign(b_host, b_host + Cout);
   if (bf && x1 && ((Cin % 8) || (Cin1 % 8))) return fail(c, "two-source bf16 conv: channel counts must be multiples of 8");
   const int Cp = bf ? (Cin + 7) & ~7 : (Cin + 3) & ~3;
-  float *xin = nullptr, *x1in = nullptr, *yout = nullptr;
+  float *xin = nullptr, *x1in = nullptr, *yout = nullptr, *vb_test = nullptr;
   int rc = 0;
   HIPCHK(c, hipMalloc(&xin, (size_t)B * H * W * Cp * 4));
   rc = (bf ? launch_nchw_to_nhwc16 : launch_nchw_to_nhwc)(x, xin, B, Cin, Cp, H, W, c->st) != hipSuccess;
@@ -1746,6 +1788,10 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
       c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
       const int Gs = bf ? (Cout / 2 + 7) & ~7 : Cout / 2;
       HIPCHK(c, hipMalloc(&yout, (size_t)B * Ho * Wo * Gs * 4));
+      if (x1in && x1_is_vector && !bf) {        // scratch of the folded vector source (the forwards take it from the workspace)
+        HIPCHK(c, hipMalloc(&vb_test, (size_t)B * 9 * 192 * 4));
+        c->vbias_ws = vb_test;
+      }
       rc = run_gconv(c, L, xin, Cp, x1in, Cin1, x1_is_vector, yout, B, H, W, nullptr, nullptr);
       if (!rc) rc = (bf ? launch_nhwc16_to_nchw : launch_nhwc_to_nchw)(yout, y, B, Cout / 2, Gs, Ho, Wo, c->st) != hipSuccess;
     }
@@ -1762,6 +1808,10 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_w16s) (void)hipFree(L.d_w16s);
   if (L.d_w96) (void)hipFree(L.d_w96);
   if (L.d_wd) (void)hipFree(L.d_wd);
+  if (L.d_u1) (void)hipFree(L.d_u1);
+  if (L.d_wv) (void)hipFree(L.d_wv);
+  if (vb_test) (void)hipFree(vb_test);
+  c->vbias_ws = nullptr;
   return rc;
 }
 

@@ -106,8 +106,15 @@ struct WinoParams {
   int xcd;             // 1: XCD-aware tile order
   unsigned div_tpi_m, div_tw_m, div_d_m;   // udiv_magic numbers for th*tw, tw and d
   int div_tpi_l, div_tw_l, div_d_l;
+  const float* vbias;  // optional [B][9][192]: per-image, per-border-configuration bias (the folded vector source, launch_vecbias)
 };
 hipError_t launch_wino(const WinoParams& p, hipStream_t st);
+// A spatially constant second source (the pooled style vector in front of conv11, editline_g.py:166-167) contributes
+//   T[b][cfg][n] = sum over the taps inside the image in border configuration cfg, sum_c W[n][C0 + c][tap] * v[b][c]
+// to output row n -- a per-image bias that depends only on WHICH taps fall inside the image (zero padding: 3 x 3 configurations
+// for a 3x3 kernel at dilation 1): cfg = 3 * (y == 0 ? 0 : y == h-1 ? 2 : 1) + (x == 0 ? 0 : x == w-1 ? 2 : 1).
+// wv: [9 taps][C1][192 packed rows] (row fastest), vec: [B][C1], T: [B][9][192].
+hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, int C1, hipStream_t st);
 // 48 -> 96 form (se_wino48.hip): src / dst NHWC 48 channels, upk [24 iterations][96 MIXED rows][32], bias [96] MIXED order
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
 // gen_deconv 96 -> 96 (48 gated), F(2x2,2x2) on the 4 sub-pixel classes (se_wino_up.hip): src NHWC 96 at (h, w), dst NHWC

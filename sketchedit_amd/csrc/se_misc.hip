@@ -536,6 +536,66 @@ __global__ void colreduce_final_kernel(const float* __restrict__ partial, float*
   out[idx] = r;
   if (out16) out16[idx] = (unsigned short)(pack_bf16x2(r, 0.f) & 0xffffu);
 }
+// launch_vecbias (se_kernels.h): grid (image, half of the 192 packed rows), 768 threads = 96 rows x 8 channel groups: a thread
+// forms the nine per-tap partial sums of its row over C1 / 8 channels (loads coalesced over the rows, independent
+// accumulators), the groups are combined through LDS in a fixed order (deterministic), and the nine border configurations
+// are sums of the per-tap values.  ~10 us per step; the round-3 first version (one thread per row, 864 dependent loads)
+// took 290.
+__global__ __launch_bounds__(768) void vecbias_kernel(const float* __restrict__ wv, const float* __restrict__ vec, float* __restrict__ T, int C1) {
+  __shared__ float red[8][9][96];
+  const int b = blockIdx.x, half = blockIdx.y;
+  const int r = threadIdx.x % 96, g = threadIdx.x / 96, n = half * 96 + r;
+  const int cg = C1 / 8;                      // channels per group (C1 % 8 == 0: checked by the launcher)
+  const float* v = vec + (size_t)b * C1 + g * cg;
+  float part[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* w = wv + ((size_t)t * C1 + g * cg) * 192 + n;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= cg; c += 4) {
+      a0 = fmaf(w[(size_t)(c + 0) * 192], v[c + 0], a0);
+      a1 = fmaf(w[(size_t)(c + 1) * 192], v[c + 1], a1);
+      a2 = fmaf(w[(size_t)(c + 2) * 192], v[c + 2], a2);
+      a3 = fmaf(w[(size_t)(c + 3) * 192], v[c + 3], a3);
+    }
+    for (; c < cg; ++c) a0 = fmaf(w[(size_t)c * 192], v[c], a0);
+    part[t] = (a0 + a1) + (a2 + a3);
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[g][t][r] = part[t];
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float a = red[0][t][r];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) a += red[k][t][r];
+      part[t] = a;
+    }
+#pragma unroll
+    for (int cy = 0; cy < 3; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 3; ++cx) {
+        float a = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const bool in = !((cy == 0 && ky == 0) || (cy == 2 && ky == 2) || (cx == 0 && kx == 0) || (cx == 2 && kx == 2));
+            if (in) a += part[ky * 3 + kx];
+          }
+        T[((size_t)b * 9 + cy * 3 + cx) * 192 + n] = a;
+      }
+  }
+}
+hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, int C1, hipStream_t st) {
+  if (C1 % 8) return hipErrorInvalidValue;
+  ProfScope ps_(st, PL_COLREDUCE);
+  hipLaunchKernelGGL(vecbias_kernel, dim3(B, 2), dim3(768), 0, st, wv, vec, T, C1);
+  return hipGetLastError();
+}
+
 hipError_t launch_colreduce(const float* x, float* partial, float* out, int B, int HW, int C, int op, hipStream_t st,
                             int x_bf16, float* out_bf16) {
   if (C > 256 || C % (x_bf16 ? 8 : 4)) return hipErrorInvalidValue;

@@ -352,11 +352,19 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
+          f32x4 bfa = bf, bga = bg;
+          if (p.vbias) {      // folded vector source (launch_vecbias): a bias that depends on the pixel's border configuration
+            const int y = y0 + a * p.d, x = x0 + bb * p.d;
+            const int cfg = 3 * (y == 0 ? 0 : (y == p.h - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.w - 1 ? 2 : 1));
+            const float* tb = p.vbias + ((size_t)b * 9 + cfg) * 192 + c0;
+            bfa += *(const f32x4*)tb;
+            bga += *(const f32x4*)(tb + 96);
+          }
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float f = of[a][bb][j][e] + bf[e];
-            const float g = og[a][bb][j][e] + bg[e];
+            const float f = of[a][bb][j][e] + bfa[e];
+            const float g = og[a][bb][j][e] + bga[e];
             const float act = act_fast(f, eluw);
             o[e] = act * sigmoid_fast(g);
           }

@@ -205,6 +205,30 @@ def test_op_low_latency_shapes_vs_oracle(eng, shape):
     assert _md(y, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("size", [(16, 16), (12, 20), (2, 8), (64, 64)], ids=lambda s: "%dx%d" % s)
+def test_op_vector_source_folded_into_bias(eng, size, monkeypatch):
+    """conv11 of netG reads cat([x, pooled style vector]) (editline_g.py:166-167): the spatially constant second source is
+    folded into a per-image, per-border-configuration bias table (launch_vecbias: nine configurations of in-bounds taps,
+    because the vector is still ZERO PADDED at the image borders) and the layer runs as the single-source Winograd kernel.
+    Against the oracle on the materialised concat, and against the two-source kernel (SE_VECBIAS=0); sizes with every
+    border configuration, a 2-row image (top and bottom rows only) and the network's own 64x64."""
+    from oracle import sketchedit_oracle as O
+    H, W = size
+    a = 1.5 / np.sqrt(192 * 9)
+    w = synth.uniform(53, "vb.w", (192, 192, 3, 3), -a, a)
+    b = synth.uniform(53, "vb.b", (192,), -0.3, 0.3)
+    x = synth.uniform(53, "vb.x%d" % H, (3, 96, H, W), -1, 1)
+    v = synth.uniform(53, "vb.v", (3, 96), -1, 1)
+    cat = np.concatenate([x, np.broadcast_to(v[:, :, None, None], (3, 96, H, W))], 1)
+    ref = O.gated_conv(torch.from_numpy(cat), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu")
+    monkeypatch.setenv("SE_VECBIAS", "1")
+    folded = eng.gated_conv2d(_cuda(x), w, b, x1=_cuda(v))
+    monkeypatch.setenv("SE_VECBIAS", "0")
+    two = eng.gated_conv2d(_cuda(x), w, b, x1=_cuda(v))
+    assert _md(folded, ref) < TOL_OP and _md(two, ref) < TOL_OP
+    assert _md(folded, two) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(5, 22, 18), (3, 22, 18), (4, 22, 18), (5, 8, 16), (3, 40, 33), (4, 16, 48), (5, 9, 70)], ids=lambda c: "c%d-%dx%d" % c)
 def test_op_first_layer_dense_k_vs_oracle(eng, case, monkeypatch):
     """The 5x5 first layers whose stored input carries padding channels (5 of NHWC8, 3 of NHWC4) in the dense-K raw-tile form
