@@ -79,6 +79,7 @@ struct Layer {
   float* d_w96 = nullptr;     // 96-row stride-1 layers: the 32-k step image of se_rconv96.hip
   float* d_u1 = nullptr;      // two-source 96+96 -> 192 layers: Winograd image of the FIRST source's 96 channels alone, and
   float* d_wv = nullptr;      //   the second source's direct weights [9 taps][96][192 packed rows] (vector source folded into a bias)
+  float* d_wv16 = nullptr;    //   the same rounded to bf16 (kept as fp32 values) for the bf16 mode
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
@@ -147,6 +148,7 @@ struct se_ctx {
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
   float* vbias_ws = nullptr;       // [B][9][192] scratch for the folded vector source of the next two-source layer (plan_netG)
+  const float* vec32 = nullptr;    // bf16 mode: the fp32 copy of the vector source (the conv source itself is its bf16 rounding)
   unsigned char* rgb8 = nullptr;   // se_inference_u8: uint8 outputs written by the last kernel of the running call
   unsigned char* m8 = nullptr;
   Profiler prof;
@@ -186,6 +188,7 @@ int fail(se_ctx* c, const char* fmt, ...) {
 // Build the LDS image [nch][NP][32] of a gated conv: row n = packed output channel, k = flattened
 // (tap, packed input channel); the 16-B slot s of row n is stored at physical slot s ^ ((n>>1)&7).
 // cin_map[pc] = checkpoint input channel of packed channel pc, or -1 for zero padding.
+float bf16_round(float f);
 bool wino_eligible_layer(const LayerDef& d);
 int pack_wino(se_ctx* c, Layer& L);
 bool wino48_eligible_layer(const LayerDef& d);
@@ -489,10 +492,14 @@ int pack_wino(se_ctx* c, Layer& L) {
     }
     if (L.d_u1) (void)hipFree(L.d_u1);
     if (L.d_wv) (void)hipFree(L.d_wv);
+    if (L.d_wv16) (void)hipFree(L.d_wv16);
     HIPCHK(c, hipMalloc(&L.d_u1, img1.size() * 4));
     HIPCHK(c, hipMalloc(&L.d_wv, wv.size() * 4));
+    HIPCHK(c, hipMalloc(&L.d_wv16, wv.size() * 4));
     HIPCHK(c, hipMemcpy(L.d_u1, img1.data(), img1.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(L.d_wv, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
+    for (auto& v : wv) v = bf16_round(v);
+    HIPCHK(c, hipMemcpy(L.d_wv16, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -688,7 +695,8 @@ int pack_net_layer(se_ctx* c, Layer& L) {
     }
     const int rc = pack_layer16(c, L, identity_map8(d.cin));
     if (rc) return rc;
-    if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && pack_rconv16(c, L)) return 1;
+    // (cin == 192: the image of the FIRST source's 96 channels, for the folded-vector form of conv11)
+    if (d.k == 3 && d.stride == 1 && !d.up && (d.cin == 96 || d.cin == 192) && d.cout == 192 && pack_rconv16(c, L)) return 1;
     if (rconv96_eligible(d) && pack_rconv96(c, L)) return 1;
   }
   // 5x5 first layers whose stored input has padding channels (5 of 8, 3 of 4): dense-K image beside the padded one
@@ -789,6 +797,26 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
   // the dominant shape (96 -> 192, 3x3, stride 1) runs in the raw-tile form when its polyphase sub-images are large
   // enough to fill 16 x 16 tiles reasonably (se_rconv16.hip); SE_RCONV16=0 keeps it on the gather-GEMM
   static const bool use_rconv = !(getenv("SE_RCONV16") && atoi(getenv("SE_RCONV16")) == 0);
+  // conv11 of netG: the spatially constant second source folded into a bias table (run_gconv / launch_vecbias), the layer on
+  // the 8 x 16 raw-tile kernel with the first source alone
+  {
+    const char* vb_env = getenv("SE_VECBIAS");
+    if (!(vb_env && atoi(vb_env) == 0) && use_rconv && !c->low_latency && src1 && src1_vec && c->vbias_ws && c->vec32 && L.d_w16s && L.d_wv16 &&
+        rconv16_small_tiles() && d.k == 3 && d.stride == 1 && d.rate == 1 && !d.up && d.cin == 192 && d.cout == 192 && C0 == 96 && C1 == 96 &&
+        Hin >= 12 && Win >= 12 && (long long)B * Hin * Win * 192 < (1ll << 31)) {
+      HIPCHK(c, launch_vecbias(L.d_wv16, c->vec32, c->vbias_ws, B, 96, c->st, 1));
+      RConvParams rp;
+      memset(&rp, 0, sizeof rp);
+      rp.src = src0; rp.wpk = L.d_w16s; rp.bias = L.d_b; rp.dst = dst; rp.vbias = c->vbias_ws;
+      rp.B = B; rp.h = Hin; rp.w = Win; rp.d = 1; rp.hs = Hin; rp.ws = Win;
+      rp.ty = (Hin + 7) / 8; rp.tx = (Win + 15) / 16;
+      rp.act = d.act; rp.xcd = xcd_remap_enabled();
+      const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+      set_launch_cost(alg, 2.0 * 2.0 * (double)B * Hin * Win * 96, d.name, 2.0 * (double)B * Hin * Win * 192.0 * 864.0);
+      HIPCHK(c, launch_rconv16(rp, c->st));
+      return 0;
+    }
+  }
   if (use_rconv && !c->low_latency && d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && !src1 && C0 == 96 &&
       (Hin % d.rate) == 0 && (Win % d.rate) == 0 && Hin / d.rate >= 12 && Win / d.rate >= 12 && L.nch16 == 14 &&
       (long long)B * Hin * Win * 192 < (1ll << 31)) {
@@ -1196,7 +1224,7 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
                                c->st, c->bf16 ? 1 : 0, c->bf16 ? vec.p : nullptr));
   P.free(xs);
   P.free(part);
-  P.free(vec32);
+  if (!c->bf16) P.free(vec32);        // bf16 mode: the fp32 vector feeds the bias table of conv11 (released after the decoder)
   if (P.side_end()) return 1;
   // ---- coarse branch :138-147
   Act xc = encoder(P, "conv", cin, nullptr);
@@ -1204,10 +1232,12 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   if (P.join()) return 1;
   float* vb = P.alloc_raw((size_t)B * 9 * 192);     // bias table of the folded style vector (run_gconv)
   if (P.rc) return P.rc;
-  c->vbias_ws = c->bf16 ? nullptr : vb;
+  c->vbias_ws = vb;
+  c->vec32 = c->bf16 ? vec32.p : nullptr;
   Act d = decoder(P, "conv", xc, vec.p, 96, 1);     // :167-175 (cat is virtual)
-  c->vbias_ws = nullptr;
+  c->vbias_ws = nullptr; c->vec32 = nullptr;
   P.release(vb);
+  if (c->bf16) P.free(vec32);
   P.free(vec);
   Act xnow = P.alloc(H, W, 4);
   if (P.rc) return P.rc;
@@ -1438,6 +1468,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
       if (kv.second.d_u1) (void)hipFree(kv.second.d_u1);
       if (kv.second.d_wv) (void)hipFree(kv.second.d_wv);
+      if (kv.second.d_wv16) (void)hipFree(kv.second.d_wv16);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
@@ -1781,16 +1812,17 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
       rc = pack_layer_dense(c, L, id);
     }
     if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
-    if (!rc && bf && k == 3 && stride == 1 && !upsample && CinT == 96 && Cout == 192 && !Cin1) rc = pack_rconv16(c, L);
+    if (!rc && bf && k == 3 && stride == 1 && !upsample && Cout == 192 && ((CinT == 96 && !Cin1) || (CinT == 192 && Cin1 == 96))) rc = pack_rconv16(c, L);
     if (!rc && bf && !Cin1 && rconv96_eligible(L.def)) rc = pack_rconv96(c, L);
     if (!rc) {
       int Ho, Wo;
       c->dry = true; run_gconv(c, L, nullptr, 0, nullptr, 0, 0, nullptr, B, H, W, &Ho, &Wo); c->dry = false;
       const int Gs = bf ? (Cout / 2 + 7) & ~7 : Cout / 2;
       HIPCHK(c, hipMalloc(&yout, (size_t)B * Ho * Wo * Gs * 4));
-      if (x1in && x1_is_vector && !bf) {        // scratch of the folded vector source (the forwards take it from the workspace)
+      if (x1in && x1_is_vector) {               // scratch of the folded vector source (the forwards take it from the workspace)
         HIPCHK(c, hipMalloc(&vb_test, (size_t)B * 9 * 192 * 4));
         c->vbias_ws = vb_test;
+        c->vec32 = bf ? x1 : nullptr;           // bf16 mode: the caller's fp32 vector (x1in is its bf16 rounding)
       }
       rc = run_gconv(c, L, xin, Cp, x1in, Cin1, x1_is_vector, yout, B, H, W, nullptr, nullptr);
       if (!rc) rc = (bf ? launch_nhwc16_to_nchw : launch_nhwc_to_nchw)(yout, y, B, Cout / 2, Gs, Ho, Wo, c->st) != hipSuccess;
@@ -1810,8 +1842,9 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_wd) (void)hipFree(L.d_wd);
   if (L.d_u1) (void)hipFree(L.d_u1);
   if (L.d_wv) (void)hipFree(L.d_wv);
+  if (L.d_wv16) (void)hipFree(L.d_wv16);
   if (vb_test) (void)hipFree(vb_test);
-  c->vbias_ws = nullptr;
+  c->vbias_ws = nullptr; c->vec32 = nullptr;
   return rc;
 }
 

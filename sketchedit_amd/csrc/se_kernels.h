@@ -114,7 +114,8 @@ hipError_t launch_wino(const WinoParams& p, hipStream_t st);
 // to output row n -- a per-image bias that depends only on WHICH taps fall inside the image (zero padding: 3 x 3 configurations
 // for a 3x3 kernel at dilation 1): cfg = 3 * (y == 0 ? 0 : y == h-1 ? 2 : 1) + (x == 0 ? 0 : x == w-1 ? 2 : 1).
 // wv: [9 taps][C1][192 packed rows] (row fastest), vec: [B][C1], T: [B][9][192].
-hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, int C1, hipStream_t st);
+// round_vec: the vector is rounded to bf16 on the way in (bf16 mode: wv then holds bf16-rounded weights; fp32 accumulate)
+hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, int C1, hipStream_t st, int round_vec = 0);
 // 48 -> 96 form (se_wino48.hip): src / dst NHWC 48 channels, upk [24 iterations][96 MIXED rows][32], bias [96] MIXED order
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
 // gen_deconv 96 -> 96 (48 gated), F(2x2,2x2) on the 4 sub-pixel classes (se_wino_up.hip): src NHWC 96 at (h, w), dst NHWC
@@ -138,6 +139,7 @@ struct RConvParams {
   int ty, tx;          // tiles per sub-image (16 x 16, or 8 rows x 16 columns)
   int act;             // 0 ELU, 1 ReLU
   int xcd;             // 1: XCD-aware tile order
+  const float* vbias;  // optional [B][9][192] fp32: folded vector source (launch_vecbias; d == 1; 8 x 16 tiles only)
 };
 hipError_t launch_rconv16(const RConvParams& p, hipStream_t st);
 bool rconv16_small_tiles();   // 8 x 16 tiles, two workgroups per CU (default) / SE_RCONV16_TILE=16

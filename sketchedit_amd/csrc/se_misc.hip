@@ -541,7 +541,7 @@ __global__ void colreduce_final_kernel(const float* __restrict__ partial, float*
 // accumulators), the groups are combined through LDS in a fixed order (deterministic), and the nine border configurations
 // are sums of the per-tap values.  ~10 us per step; the round-3 first version (one thread per row, 864 dependent loads)
 // took 290.
-__global__ __launch_bounds__(768) void vecbias_kernel(const float* __restrict__ wv, const float* __restrict__ vec, float* __restrict__ T, int C1) {
+__global__ __launch_bounds__(768) void vecbias_kernel(const float* __restrict__ wv, const float* __restrict__ vec, float* __restrict__ T, int C1, int round_vec) {
   __shared__ float red[8][9][96];
   const int b = blockIdx.x, half = blockIdx.y;
   const int r = threadIdx.x % 96, g = threadIdx.x / 96, n = half * 96 + r;
@@ -553,13 +553,14 @@ __global__ __launch_bounds__(768) void vecbias_kernel(const float* __restrict__ 
     const float* w = wv + ((size_t)t * C1 + g * cg) * 192 + n;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int c = 0;
+    auto vv = [&](int i) { return round_vec ? bf16_lo(pack_bf16x2(v[i], 0.f) & 0xffffu) : v[i]; };
     for (; c + 4 <= cg; c += 4) {
-      a0 = fmaf(w[(size_t)(c + 0) * 192], v[c + 0], a0);
-      a1 = fmaf(w[(size_t)(c + 1) * 192], v[c + 1], a1);
-      a2 = fmaf(w[(size_t)(c + 2) * 192], v[c + 2], a2);
-      a3 = fmaf(w[(size_t)(c + 3) * 192], v[c + 3], a3);
+      a0 = fmaf(w[(size_t)(c + 0) * 192], vv(c + 0), a0);
+      a1 = fmaf(w[(size_t)(c + 1) * 192], vv(c + 1), a1);
+      a2 = fmaf(w[(size_t)(c + 2) * 192], vv(c + 2), a2);
+      a3 = fmaf(w[(size_t)(c + 3) * 192], vv(c + 3), a3);
     }
-    for (; c < cg; ++c) a0 = fmaf(w[(size_t)c * 192], v[c], a0);
+    for (; c < cg; ++c) a0 = fmaf(w[(size_t)c * 192], vv(c), a0);
     part[t] = (a0 + a1) + (a2 + a3);
   }
 #pragma unroll
@@ -589,10 +590,10 @@ __global__ __launch_bounds__(768) void vecbias_kernel(const float* __restrict__ 
       }
   }
 }
-hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, int C1, hipStream_t st) {
+hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, int C1, hipStream_t st, int round_vec) {
   if (C1 % 8) return hipErrorInvalidValue;
   ProfScope ps_(st, PL_COLREDUCE);
-  hipLaunchKernelGGL(vecbias_kernel, dim3(B, 2), dim3(768), 0, st, wv, vec, T, C1);
+  hipLaunchKernelGGL(vecbias_kernel, dim3(B, 2), dim3(768), 0, st, wv, vec, T, C1, round_vec);
   return hipGetLastError();
 }
 

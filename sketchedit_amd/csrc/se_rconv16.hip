@@ -313,11 +313,19 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     char* o = Raw + ((4 * pg + pt) * 16 + jx) * OPX;
+    // folded vector source (launch_vecbias; dilation 1): a bias that depends on the pixel's border configuration
+    const float* tb = nullptr;
+    if (p.vbias) {
+      const int y = min(ty0 + 4 * pg + pt, p.h - 1), x = min(tx0 + jx, p.w - 1);
+      const int cfg = 3 * (y == 0 ? 0 : (y == p.h - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.w - 1 ? 2 : 1));
+      tb = p.vbias + ((size_t)b * 9 + cfg) * 192;
+    }
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       const int c0 = (nh * 3 + nt) * 16 + q * 4;
-      const f32x4 bf = *(const f32x4*)(p.bias + c0);
-      const f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
+      f32x4 bf = *(const f32x4*)(p.bias + c0);
+      f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
+      if (tb) { bf += *(const f32x4*)(tb + c0); bg += *(const f32x4*)(tb + 96 + c0); }
       float ov[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
