@@ -409,7 +409,9 @@ int pack_rconv16(se_ctx* c, Layer& L) {
 // [class][step][6 row tiles][16 rows][32 k], k = granule (8 channels) index tap * CG + cg, four granules per step; rows in
 // the N=96 order (features, then gates); granule g of row r at slot g ^ F[r >> 2], F = {0, 2, 3, 1}.
 bool rconv96_eligible(const LayerDef& d) {
-  if (d.cout != 96 || d.stride != 1 || d.rate != 1 || d.k != 3 || d.act == ACT_NONE) return false;
+  if (d.cout != 96 || d.rate != 1 || d.k != 3 || d.act == ACT_NONE) return false;
+  if (d.stride == 2) return !d.up && d.cin == 24;                     // stride 2: the 24 -> 96 downsampling layers
+  if (d.stride != 1) return false;
   return d.up ? d.cin == 96 : (d.cin == 48 || d.cin == 24);
 }
 int pack_rconv96(se_ctx* c, Layer& L) {
@@ -840,12 +842,13 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
     memset(&rp, 0, sizeof rp);
     rp.src = src0; rp.wpk = L.d_w96; rp.bias = L.d_b; rp.dst = dst;
     rp.B = B; rp.h = Hin; rp.w = Win; rp.CG = C0 / 8;
-    rp.ty = (Hin + 15) / 16; rp.tx = (Win + 15) / 16;
+    rp.stride = d.stride; rp.oh = Ho; rp.ow = Wo;
+    rp.ty = ((d.stride == 2 ? Ho : Hin) + 15) / 16; rp.tx = ((d.stride == 2 ? Wo : Win) + 15) / 16;
     rp.up2 = d.up ? 1 : 0; rp.act = d.act; rp.xcd = xcd_remap_enabled();
     const int T = d.up ? 4 : 9, nstep = (T * rp.CG + 3) / 4;
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
     set_launch_cost(alg, 2.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * 48), d.name,
-                    2.0 * (double)B * Hin * Win * (d.up ? 4.0 : 1.0) * 96.0 * (nstep * 32.0));
+                    2.0 * (double)B * (d.stride == 2 ? (double)Ho * Wo : (double)Hin * Win) * (d.up ? 4.0 : 1.0) * 96.0 * (nstep * 32.0));
     HIPCHK(c, launch_rconv96(rp, c->st));
     return 0;
   }

@@ -153,7 +153,8 @@ struct RConv96Params {
   void* dst;           // bf16 NHWC [B][h][w][48], or [B][2h][2w][48] for gen_deconv
   int B, h, w;         // source size
   int CG;              // 8-channel granules per source pixel (3, 6, 12)
-  int ty, tx;          // 16 x 16 tiles of the source grid
+  int ty, tx;          // 16 x 16 tiles of the source grid (stride 2: of the OUTPUT grid)
+  int stride, oh, ow;  // 1, or 2 with the output size (3x3, 24 -> 96: de-interleaved raw tile, se_rconv96.hip)
   int up2;             // gen_deconv: four 2x2 sub-pixel classes
   int act;             // 0 ELU, 1 ReLU
   int xcd;             // 1: XCD-aware tile order

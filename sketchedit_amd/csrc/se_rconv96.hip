@@ -20,11 +20,16 @@
 
 namespace se {
 
-template <int CG, int P, int KW, bool UP>
+template <int CG, int P, int KW, bool UP, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) {
-  constexpr int TS = 16, RS = TS + KW - 1;            // tile side, raw (halo) tile side
-  constexpr int PIXB = P * 16, ROWB = RS * PIXB;
-  constexpr int SLOTS = RS * RS * P;
+  constexpr int TS = 16, RS = STRIDE * (TS - 1) + KW;   // tile side (outputs), raw (halo) tile side (source pixels)
+  // STRIDE 2: a tile row is stored de-interleaved by column parity -- [even columns | odd columns] -- so that the columns
+  // 2 j + kx one fragment read touches (all of one parity) are CONSECUTIVE pixels of a plane: pixel-major with a stride of
+  // two pixels every ds_read_b128 would be a 4-way bank conflict whatever the padding (2 * P * 4 dwords is a multiple of 8)
+  constexpr int HALF = (RS + 1) / 2;                     // pixels per parity plane of a row
+  constexpr int RSP = STRIDE == 2 ? 2 * HALF : RS;       // stored pixels per row
+  constexpr int PIXB = P * 16, ROWB = RSP * PIXB;
+  constexpr int SLOTS = RS * RSP * P;
   constexpr int NDMA = (SLOTS + 63) / 64;
   constexpr int RAWB = NDMA * 1024;
   constexpr int WSB = 6 * 1024;                       // one 32-k weight step: 6 row tiles of 1 KB
@@ -68,10 +73,11 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
     if (i < NDMA) {
       const int q = i * 64 + lane;                   // granule slot of the raw tile
       const int pix = q / P, gs = q - pix * P;
-      const int row = pix / RS, c = pix - row * RS;
+      const int row = pix / RSP, cs = pix - row * RSP;               // stored column
+      const int c = STRIDE == 2 ? 2 * (cs % HALF) + cs / HALF : cs;    // source column of the tile (parity planes)
       const int gl = CG == 12 ? gs ^ (((c >> 2) & 1) << 1) : gs;     // stored slot gs holds logical granule gl
-      const int sy = ty0 - pady + row, sx = tx0 - padx + c;
-      const bool ok = q < SLOTS && gs < CG && (unsigned)sy < (unsigned)p.h && (unsigned)sx < (unsigned)p.w;
+      const int sy = STRIDE * ty0 - pady + row, sx = STRIDE * tx0 - padx + c;
+      const bool ok = q < SLOTS && gs < CG && c < RS && (unsigned)sy < (unsigned)p.h && (unsigned)sx < (unsigned)p.w;
       const unsigned off = (unsigned)((b * p.h + sy) * p.w + sx) * (unsigned)(CG * 16) + (unsigned)gl * 16u;
       bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);      // outside the image / pad granule: zero fill
     }
@@ -86,9 +92,10 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
     const int gi = min(s * 4 + g4, NG - 1);          // K padding (zero weights): any valid address
     const int tap = gi / CG, cg = gi - tap * CG;
     const int ky = tap / KW, kx = tap - ky * KW;
-    const int c = jx + kx;
+    const int c = STRIDE * jx + kx;                                  // source column inside the tile
+    const int cs = STRIDE == 2 ? (c & 1) * HALF + (c >> 1) : c;        // its stored position
     const int slot = CG == 12 ? cg ^ (((c >> 2) & 1) << 1) : cg;
-    boff[s] = ky * ROWB + c * PIXB + slot * 16;
+    boff[s] = ky * ROWB + cs * PIXB + slot * 16;
   }
   const int pg = w;                                   // wave = all 96 rows x tile rows 4 pg .. 4 pg + 3
   constexpr int NTW = 6, PT = 4;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto bfrag = [&](int s, int pt) -> bf16x8 { return *(const bf16x8*)(Raw + (4 * pg + pt) * ROWB + boff[s]); };
+  auto bfrag = [&](int s, int pt) -> bf16x8 { return *(const bf16x8*)(Raw + STRIDE * (4 * pg + pt) * ROWB + boff[s]); };
   auto afrag = [&](int s, int i) -> bf16x8 { return *(const bf16x8*)(Wb + (s % NS) * WSB + aoff + i * 1024); };
   if (NSTEP > 1) wait_newest_step();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,38 +165,39 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
     }
   }
   __syncthreads();
-  const int OW = UP ? 2 * p.w : p.w, OH = UP ? 2 * p.h : p.h;
+  const int OW = UP ? 2 * p.w : (STRIDE == 2 ? p.ow : p.w), OH = UP ? 2 * p.h : (STRIDE == 2 ? p.oh : p.h);
 #pragma unroll
   for (int it = 0; it < 6; ++it) {                  // 256 pixels x 6 pieces of 16 bytes = 6 per thread
     const int piece = it * 256 + tid;
     const int pix = piece / 6, part = piece - pix * 6;
     const int sy = ty0 + (pix >> 4), sx = tx0 + (pix & 15);
-    if (sy < p.h && sx < p.w) {
+    if (sy < (STRIDE == 2 ? OH : p.h) && sx < (STRIDE == 2 ? OW : p.w)) {
       const int oy = UP ? 2 * sy + py : sy, ox = UP ? 2 * sx + px : sx;
       *(uint4*)((char*)p.dst + ((size_t)(b * OH + oy) * OW + ox) * 96 + part * 16) = *(const uint4*)(Raw + pix * OPX + part * 16);
     }
   }
 }
 
-template <int CG, int P, int KW, bool UP>
+template <int CG, int P, int KW, bool UP, int STRIDE = 1>
 static hipError_t launch_rconv96_t(const RConv96Params& p, hipStream_t st) {
-  constexpr int RS = 16 + KW - 1;
-  constexpr int RAWB = ((RS * RS * P + 63) / 64) * 1024;
+  constexpr int RS = STRIDE * 15 + KW, RSP = STRIDE == 2 ? 2 * ((RS + 1) / 2) : RS;
+  constexpr int RAWB = ((RS * RSP * P + 63) / 64) * 1024;
   static_assert(RAWB >= 256 * 112, "the epilogue transposes the gated tile in the raw tile's room");
   constexpr int LDS = RAWB + 3 * 6 * 1024;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-  hipError_t e = ensure_max_lds((const void*)rconv96_kernel<CG, P, KW, UP>, LDS);
+  hipError_t e = ensure_max_lds((const void*)rconv96_kernel<CG, P, KW, UP, STRIDE>, LDS);
   if (e != hipSuccess) return e;
   const int tiles = p.B * p.ty * p.tx;
   const int grid = UP ? class_tile_grid(tiles) : tiles;
   set_launch_grid(grid);
   ProfScope ps_(st, PL_GCONV_N96);
-  hipLaunchKernelGGL((rconv96_kernel<CG, P, KW, UP>), dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((rconv96_kernel<CG, P, KW, UP, STRIDE>), dim3(grid), dim3(256), LDS, st, p);
   return hipGetLastError();
 }
 
 hipError_t launch_rconv96(const RConv96Params& p, hipStream_t st) {
   if (p.up2) return p.CG == 12 ? launch_rconv96_t<12, 12, 2, true>(p, st) : hipErrorInvalidValue;
+  if (p.stride == 2) return p.CG == 3 ? launch_rconv96_t<3, 3, 3, false, 2>(p, st) : hipErrorInvalidValue;
   if (p.CG == 6) return launch_rconv96_t<6, 6, 3, false>(p, st);
   if (p.CG == 3) return launch_rconv96_t<3, 6, 3, false>(p, st);
   return hipErrorInvalidValue;
