@@ -791,6 +791,13 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
 // ---- bf16 mode: every gated conv is the direct gather-GEMM on v_mfma_f32_16x16x32_bf16 (se_gconv.hip, BF16) -----------
 // (The Winograd transforms would have to run in fp32 on bf16 data and round the transformed tiles again; at 16x the
 // MFMA rate the layers are bound by the LDS fill, not by multiply-adds, so there is nothing for them to buy.)
+// two polyphase sub-images of 8 columns (and at most 8 rows) share one 8 x 16 raw tile (rconv16b_kernel, p.dual)
+static bool rconv16_dual_ok(const Layer& L, const LayerDef& d, int Hin, int Win) {
+  const char* e = getenv("SE_RCONV16_DUAL");             // (read per call: the tests compare both forms in one process)
+  if (e && atoi(e) == 0) return false;
+  return rconv16_small_tiles() && L.d_w16s && (d.rate % 2) == 0 && Win / d.rate == 8 && Hin / d.rate <= 8 && Hin / d.rate >= 4;
+}
+
 int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const float* src1, int C1, int src1_vec, float* dst,
                 int B, int Hin, int Win, int Ho, int Wo, int pad) {
   const LayerDef& d = L.def;
@@ -820,11 +827,13 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
     }
   }
   if (use_rconv && !c->low_latency && d.k == 3 && d.stride == 1 && !d.up && d.cin == 96 && d.cout == 192 && !src1 && C0 == 96 &&
-      (Hin % d.rate) == 0 && (Win % d.rate) == 0 && Hin / d.rate >= 12 && Win / d.rate >= 12 && L.nch16 == 14 &&
-      (long long)B * Hin * Win * 192 < (1ll << 31)) {
+      (Hin % d.rate) == 0 && (Win % d.rate) == 0 && L.nch16 == 14 && (long long)B * Hin * Win * 192 < (1ll << 31) &&
+      ((Hin / d.rate >= 12 && Win / d.rate >= 12) || rconv16_dual_ok(L, d, Hin, Win))) {
     RConvParams rp;
     memset(&rp, 0, sizeof rp);
     const bool small = rconv16_small_tiles() && L.d_w16s;     // 8 x 16 tiles, 32-k step image, no K padding
+    // sub-images of 8 x 8 (dilation 16 at 128 x 128, 8 at 64 x 64): two phases share an 8 x 16 tile (SE_RCONV16_DUAL=0: gather-GEMM)
+    rp.dual = !(Hin / d.rate >= 12 && Win / d.rate >= 12);
     rp.src = src0; rp.wpk = small ? L.d_w16s : L.d_w16; rp.bias = L.d_b; rp.dst = dst;
     rp.B = B; rp.h = Hin; rp.w = Win; rp.d = d.rate; rp.hs = Hin / d.rate; rp.ws = Win / d.rate;
     rp.ty = small ? (rp.hs + 7) / 8 : (rp.hs + 15) / 16; rp.tx = (rp.ws + 15) / 16;

@@ -140,6 +140,7 @@ struct RConvParams {
   int act;             // 0 ELU, 1 ReLU
   int xcd;             // 1: XCD-aware tile order
   const float* vbias;  // optional [B][9][192] fp32: folded vector source (launch_vecbias; d == 1; 8 x 16 tiles only)
+  int dual;            // 8 x 16 tiles only: ws == 8, d even -- two phases (py, px), (py, px + 1) side by side in one tile
 };
 hipError_t launch_rconv16(const RConvParams& p, hipStream_t st);
 bool rconv16_small_tiles();   // 8 x 16 tiles, two workgroups per CU (default) / SE_RCONV16_TILE=16

@@ -216,10 +216,17 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   const float eluw = p.act == 0 ? 1.f : 0.f;      // act_fast: ELU weight of the gated epilogue (wave-uniform)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lb = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int tpi = p.ty * p.tx, per_img = p.d * p.d * tpi;
+  // p.dual (sub-images 8 columns wide, e.g. dilation 16 on a 128 x 128 map): a tile holds the phases (py, px) and
+  // (py, px + 1) side by side.  Raw columns: 0 = zero | 1..8 = phase px | 9 = zero (right halo of the first, left halo of
+  // the second) | 10..17 = phase px + 1; the second one's right halo, "column 18", is column 0 of the next raw row --
+  // also zero (after the last row: the zero-filled slack of the last DMA).  Pixel column jx of the MFMA tile is raw
+  // column jx + 1 (jx < 8) or jx + 2: a per-lane constant in the fragment address, nothing in the loop changes.
+  const int dual = p.dual;
+  const int dxp = dual ? p.d >> 1 : p.d;              // phases (pairs) along x
+  const int tpi = p.ty * p.tx, per_img = p.d * dxp * tpi;
   const int b = lb / per_img, r1 = lb - b * per_img;
   const int ph = r1 / tpi, t = r1 - ph * tpi;
-  const int py = ph / p.d, px = ph - py * p.d;
+  const int py = ph / dxp, px = (ph - py * dxp) << dual;
   const int ty0 = (t / p.tx) * TY, tx0 = (t % p.tx) * TX;
 
   const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.h * p.w * 192u);
@@ -238,9 +245,11 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
       const int pix = q / 12, gs = q - pix * 12;
       const int row = pix / RSX, c = pix - row * RSX;
       const int gl = gs ^ (((c >> 2) & 1) << 1);     // stored slot gs holds logical granule gl (layout note at the top)
-      const int sy = ty0 - 1 + row, sx = tx0 - 1 + c;
+      const int sy = ty0 - 1 + row;
+      const int second = dual && c >= 10;             // (dual: c = 9 gives sx = 8 = ws, the shared zero column)
+      const int sx = dual ? (second ? c - 10 : c - 1) : tx0 - 1 + c;
       const bool ok = q < RSY * RSX * 12 && (unsigned)sy < (unsigned)p.hs && (unsigned)sx < (unsigned)p.ws;
-      const unsigned off = (unsigned)((b * p.h + sy * p.d + py) * p.w + sx * p.d + px) * 192u + (unsigned)gl * 16u;
+      const unsigned off = (unsigned)((b * p.h + sy * p.d + py) * p.w + sx * p.d + px + second) * 192u + (unsigned)gl * 16u;
       bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);
     }
   }
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   int bk[3];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
-    const int c = (lane & 15) + kx;
+    const int c = (lane & 15) + kx + (dual && (lane & 8) ? 1 : 0);
     bk[kx] = c * 192 + (((lane >> 4) ^ (((c >> 2) & 1) << 1)) << 4);
   }
   const int nh = w & 1, pg = w >> 1;                  // wave = 96 packed rows (3 feature tiles + their gate tiles) x 64 pixels
@@ -341,9 +350,10 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   for (int it = 0; it < 6; ++it) {                  // 128 pixels x 12 pieces of 16 bytes = 6 per thread
     const int piece = it * 256 + tid;
     const int pix = piece / 12, part = piece - pix * 12;
-    const int sy = ty0 + (pix >> 4), sx = tx0 + (pix & 15);
+    const int col = pix & 15;
+    const int sy = ty0 + (pix >> 4), sx = dual ? (col & 7) : tx0 + col, pxx = px + (dual ? col >> 3 : 0);
     if (sy < p.hs && sx < p.ws)
-      *(uint4*)((char*)p.dst + ((size_t)(b * p.h + sy * p.d + py) * p.w + sx * p.d + px) * 192 + part * 16) =
+      *(uint4*)((char*)p.dst + ((size_t)(b * p.h + sy * p.d + py) * p.w + sx * p.d + pxx) * 192 + part * 16) =
           *(const uint4*)(Raw + pix * OPX + part * 16);
   }
 }
@@ -358,7 +368,7 @@ hipError_t launch_rconv16(const RConvParams& p, hipStream_t st) {
     constexpr int LDS = 34 * 1024 + 3 * 12 * 1024;   // raw tile 34 KB + ring of three 12 KB weight steps
     hipError_t e = ensure_max_lds((const void*)rconv16b_kernel, LDS);
     if (e != hipSuccess) return e;
-    const int grid = p.B * p.d * p.d * p.ty * p.tx;
+    const int grid = p.B * p.d * (p.dual ? p.d / 2 : p.d) * p.ty * p.tx;
     set_launch_grid(grid);
     ProfScope ps_(st, PL_GCONV_N192);
     hipLaunchKernelGGL(rconv16b_kernel, dim3(grid), dim3(256), LDS, st, p);

@@ -90,7 +90,9 @@ def test_op_gated_conv_bf16(eng, shape, ll):
 
 
 RCONV = [(1, 16, 16, "elu"), (1, 32, 48, "relu"), (1, 22, 18, "elu"), (2, 24, 32, "elu"), (4, 48, 64, "elu"), (2, 36, 28, "elu"),
-         (1, 12, 12, "elu"), (8, 128, 96, "elu")]
+         (1, 12, 12, "elu"), (8, 128, 96, "elu"),
+         # sub-images 8 columns wide: two phases share an 8 x 16 tile (p.dual) -- full 8 x 8, ragged rows, dilation 16 at 128 x 128
+         (4, 32, 32, "elu"), (8, 64, 64, "relu"), (8, 48, 64, "elu"), (16, 128, 128, "elu"), (2, 8, 16, "elu")]
 
 
 @pytest.mark.parametrize("case", RCONV, ids=["d%d-%dx%d-%s" % c for c in RCONV])
