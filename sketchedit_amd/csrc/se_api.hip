@@ -302,7 +302,9 @@ int pack_layer_dense(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
       const int tap = kf / Cd, ic = cin_map[kf % Cd], ty = tap / d.k, tx = tap % d.k;
       const int ch = kf / 32;
       int kin = kf % 32;
-      if (ch == nch - 1) {                       // dense_kin: j-th real k of the last chunk -> k-step j / 4, lane group j % 4
+      {      // dense_kin: j-th k of a chunk -> k-step j / 4, lane group j % 4 (instruction-major).  In the last chunk that packs the
+             // real k into the first k-steps (the others are not issued); in every chunk it makes the four lane groups of one
+             // k-step read four CONSECUTIVE dwords of the dense tile (bank-conflict-free; k-major order: 32-50 % conflict cycles)
         const int j = kin, step = j / 4, g = j % 4;
         kin = (step / 4) * 16 + g * 4 + (step % 4);
       }

@@ -215,16 +215,18 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
       const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)ch * 4u;
       bufdma4(ok ? off : 0x80000000u, rsrc, lds_raw + i * 256);
     }
-    // chunk slot -> byte offset of its k's (tap, channel) inside the dense tile.  In the LAST chunk the real k are packed
-    // instruction-major (dense_kin, mirrored by pack_layer_dense), so that only ceil(REM / 4) of its 8 MFMA k-steps carry
-    // data and the others are not issued at all; unused slots (zero weights, never multiplied) get any valid offset.
+    // chunk slot -> byte offset of its k's (tap, channel) inside the dense tile.  The k of a chunk are laid out
+    // instruction-major (dense_kin, mirrored by pack_layer_dense): k-step s of the chunk multiplies k = 4 s + lane group.
+    // The four lane groups of a ds_read_b32 then read four consecutive dwords of the dense tile per pixel -- with the
+    // k-major order they read a stride of four, which with 4 channels per pixel put 64 lanes on 8 banks (50 % conflict
+    // cycles, 32 % with 3 / 5 channels) -- and in the LAST chunk only ceil(REM / 4) of the 8 k-steps carry data, the
+    // others are not issued at all; unused slots (zero weights, never multiplied) get any valid offset.
     if (tid < NCH * 32) {
       int kf = K - 1;
-      if (tid < (NCH - 1) * 32) kf = tid;
-      else {
-        const int kin = tid - (NCH - 1) * 32, half = kin >> 4, g = (kin >> 2) & 3, r = kin & 3;
-        const int j = (half * 4 + r) * 4 + g;               // inverse of dense_kin
-        if (j < REM) kf = (NCH - 1) * 32 + j;
+      {
+        const int chk = tid >> 5, kin = tid & 31, half = kin >> 4, g = (kin >> 2) & 3, r = kin & 3;
+        const int j = (half * 4 + r) * 4 + g;               // inverse of dense_kin (every chunk: see pack_layer_dense)
+        if (chk < NCH - 1 || j < REM) kf = chk * 32 + j;
       }
       const int tap = kf / CD, ch = kf - tap * CD, ky = tap / KW, kx = tap - ky * KW;
       Tab[tid] = ky * ROWB + (kx * CD + ch) * 4;
