@@ -95,14 +95,17 @@ DEVFN float elu_fast(float x) {
   return x > 0.f ? x : e;
 }
 DEVFN float sigmoid_fast(float x) { return fast_rcp(1.f + fast_exp(-x)); }
-// ELU / ReLU of the gated epilogues without a branch or a select on the activation type: act(x) = max(x, 0) + w (e^min(x, 0) - 1)
-// with the wave-uniform weight w = 1 (ELU) or 0 (ReLU).  Exact for x >= 0 (e^0 - 1 = 0), the former elu_fast(x) for x < 0.
-// (`p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)` compiled to two scalar branches PER VALUE in the 48-value bf16 epilogues.)
+// ELU / ReLU of the gated epilogues without a branch or a select on the activation type:
+//   act(x) = max(x, w (e^min(x, 0) - 1)),   wave-uniform weight w = 1 (ELU) or 0 (ReLU).
+// x >= 0: the second operand is 0 <= x.  x < 0: e^x - 1 > x, so the maximum is the ELU branch (where rounding puts the
+// computed e^x - 1 a hair below x -- |x| < 3e-4 -- the result is x, inside the error of the exponential itself).
+// Four ordinary VALU instructions (mul, med3, fma, med3) + v_exp_f32; the ordinary ones are what an MFMA kernel pays for
+// (they exclude MFMAs on the SIMD, the transcendental does not).  The former max(x,0) + w (e^min(x,0) - 1)
+// was five.  (`p.act == 0 ? elu_fast(f) : fmaxf(f, 0.f)` compiled to two scalar branches PER VALUE in the 48-value bf16 epilogues.)
 DEVFN float act_fast(float x, float eluw) {
-  const float pos = __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());       // max(x, 0) in one instruction
-  const float neg = __builtin_amdgcn_fmed3f(x, -__builtin_inff(), 0.f);      // min(x, 0)
-  const float e = __builtin_amdgcn_exp2f(neg * 1.44269504088896340736f) - 1.f;
-  return fmaf(eluw, e, pos);
+  const float n = __builtin_amdgcn_fmed3f(x * 1.44269504088896340736f, -__builtin_inff(), 0.f);      // min(x log2 e, 0)
+  const float neg = fmaf(__builtin_amdgcn_exp2f(n), eluw, -eluw);                                   // w (e^min(x,0) - 1)
+  return __builtin_amdgcn_fmed3f(x, neg, __builtin_inff());                                         // max(x, neg)
 }
 // tanh(x) = 1 - 2 / (1 + e^(2x)): saturates correctly (e^(2x) -> inf gives 1, -> 0 gives -1); absolute error ~2e-7 -- ocml's
 // tanhf costs ~40 VALU instructions, a third of small_conv_kernel<3>'s multiply-add work
