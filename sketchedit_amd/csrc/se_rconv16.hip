@@ -267,11 +267,15 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   const int rq = (lane & 15) >> 2;
   const int aoff = (lane & 15) * 64 + (((lane >> 4) ^ ((0x78 >> (rq * 2)) & 3)) << 4) + nh * 3 * 1024;
 
+  // The accumulators start at the bias (rows 4 (lane >> 4) .. + 3 of each row tile): the epilogue has no bias add --
+  // every ordinary VALU instruction there is paid in MFMA slots
   f32x4 acc[NTW][PT];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt)
+  for (int nt = 0; nt < NTW; ++nt) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + (nt < 3 ? 0 : 96) + (nh * 3 + (nt < 3 ? nt : nt - 3)) * 16 + (lane >> 4) * 4);
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = b4;
+  }
 
   auto bfrag = [&](int s, int pt) -> bf16x8 {          // s = 32-k step (compile-time): tap s / 3, channels 32 (s % 3) ..
     const int tap = s / 3, kk = s - tap * 3, ky = tap / 3, kx = tap - ky * 3;
@@ -332,16 +336,11 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       const int c0 = (nh * 3 + nt) * 16 + q * 4;
-      f32x4 bf = *(const f32x4*)(p.bias + c0);
-      f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
-      if (tb) { bf += *(const f32x4*)(tb + c0); bg += *(const f32x4*)(tb + 96 + c0); }
+      f32x4 vf = acc[nt][pt], vg = acc[nt + 3][pt];                 // (bias already inside)
+      if (tb) { vf += *(const f32x4*)(tb + c0); vg += *(const f32x4*)(tb + 96 + c0); }
       float ov[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float f = acc[nt][pt][r] + bf[r];
-        const float g = acc[nt + 3][pt][r] + bg[r];
-        ov[r] = act_fast(f, eluw) * sigmoid_fast(g);
-      }
+      for (int r = 0; r < 4; ++r) ov[r] = act_fast(vf[r], eluw) * sigmoid_fast(vg[r]);
       *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
     }
   }

@@ -102,11 +102,14 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
   const int rq = (lane & 15) >> 2;
   const int aoff = (lane & 15) * 64 + (((lane >> 4) ^ ((0x78 >> (rq * 2)) & 3)) << 4);      // swizzle F = {0,2,3,1}[row >> 2]
 
+  // accumulators start at the bias: no bias add in the epilogue (its ordinary VALU instructions cost MFMA slots)
   f32x4 acc[NTW][PT];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt)
+  for (int nt = 0; nt < NTW; ++nt) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + nt * 16 + (lane >> 4) * 4);      // row tiles 0-2 features, 3-5 gates: bias[48 + ...]
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = b4;
+  }
 
   auto bfrag = [&](int s, int pt) -> bf16x8 { return *(const bf16x8*)(Raw + STRIDE * (4 * pg + pt) * ROWB + boff[s]); };
   auto afrag = [&](int s, int i) -> bf16x8 { return *(const bf16x8*)(Wb + (s % NS) * WSB + aoff + i * 1024); };
@@ -152,15 +155,9 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       const int c0 = nt * 16 + q * 4;
-      const f32x4 bf = *(const f32x4*)(p.bias + c0);
-      const f32x4 bg = *(const f32x4*)(p.bias + 48 + c0);
       float ov[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float f = acc[nt][pt][r] + bf[r];
-        const float g = acc[nt + 3][pt][r] + bg[r];
-        ov[r] = act_fast(f, eluw) * sigmoid_fast(g);
-      }
+      for (int r = 0; r < 4; ++r) ov[r] = act_fast(acc[nt][pt][r], eluw) * sigmoid_fast(acc[nt + 3][pt][r]);      // (bias already inside)
       *(uint2*)(o + c0 * 2) = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
     }
   }
