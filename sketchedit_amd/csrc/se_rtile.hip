@@ -74,11 +74,14 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   const int rowb = p.RW * pixb;                                          // bytes per raw tile row
   const int xbase = ((PT * w) * p.RW + jx) * pixb;                        // this lane's pixel of the wave's first row
 
+  // accumulators start at the bias: the epilogue has no bias add (its ordinary VALU instructions cost MFMA slots)
   f32x4 acc[NT][PT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt) {
+    const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + g4 * 4);
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = bq;
+  }
 
   dma_wait_all();
   __syncthreads();
@@ -140,11 +143,10 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
     constexpr bool ELU = decltype(elu_tag)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
       const bool okc = okx && nt * 8 + lanec < p.G;
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        const f32x4 v = acc[nt][pt] + bq;
+        const f32x4 v = acc[nt][pt];                                    // (bias already inside)
         const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
         const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
         const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
@@ -237,11 +239,13 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
   const int jx = lane & 15, g4 = lane >> 4;
   const int xbase = ((PT * w) * RW + jx) * CD * 4;          // this lane's pixel of the wave's first row
 
-  f32x4 acc[NT][PT];
+  f32x4 acc[NT][PT];                                        // start at the bias (rtile_kernel)
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt) {
+    const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + g4 * 4);
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = bq;
+  }
 
   dma_wait_all();
   __syncthreads();
@@ -281,11 +285,10 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
-    const f32x4 bq = *(const f32x4*)(p.bias + nt * 16 + q * 4);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int yy = ty0 + PT * w + pt, xx = tx0 + jx;
-      const f32x4 v = acc[nt][pt] + bq;
+      const f32x4 v = acc[nt][pt];                          // (bias already inside)
       const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
       const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);

@@ -179,12 +179,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   f32x4 af[3], ag[3];                  // position accumulators (feature / gate tiles)
   f32x4 of[2][2][3], og[2][2][3];      // output accumulators (a, b, tile)
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < 3; ++j) {      // the output accumulators start at the bias: one add less per value in the epilogue
     af[j] = ag[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 bf0 = *(const f32x4*)(p.bias + (3 * chh + j) * 16 + (lane >> 4) * 4);
+    const f32x4 bg0 = *(const f32x4*)(p.bias + 96 + (3 * chh + j) * 16 + (lane >> 4) * 4);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) of[a][b][j] = og[a][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 2; ++b) { of[a][b][j] = bf0; og[a][b][j] = bg0; }
   }
   // fold the finished position accumulators: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1].
   // xi and nu are compile-time in the unrolled loop: only the non-zero terms exist, as packed adds / fmas.
@@ -346,28 +348,21 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int c0 = (3 * chh + j) * 16 + q * 4;
-      const f32x4 bf = *(const f32x4*)(p.bias + c0);
-      const f32x4 bg = *(const f32x4*)(p.bias + 96 + c0);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          f32x4 bfa = bf, bga = bg;
+          f32x4 vf = of[a][bb][j], vg = og[a][bb][j];      // (layer bias already inside)
           if (p.vbias) {      // folded vector source (launch_vecbias): a bias that depends on the pixel's border configuration
             const int y = y0 + a * p.d, x = x0 + bb * p.d;
             const int cfg = 3 * (y == 0 ? 0 : (y == p.h - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.w - 1 ? 2 : 1));
             const float* tb = p.vbias + ((size_t)b * 9 + cfg) * 192 + c0;
-            bfa += *(const f32x4*)tb;
-            bga += *(const f32x4*)(tb + 96);
+            vf += *(const f32x4*)tb;
+            vg += *(const f32x4*)(tb + 96);
           }
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float f = of[a][bb][j][e] + bfa[e];
-            const float g = og[a][bb][j][e] + bga[e];
-            const float act = act_fast(f, eluw);
-            o[e] = act * sigmoid_fast(g);
-          }
+          for (int e = 0; e < 4; ++e) o[e] = act_fast(vf[e], eluw) * sigmoid_fast(vg[e]);
           *(f32x4*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 96 + c0) = o;
         }
     }
