@@ -141,10 +141,12 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       am[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // the output accumulators start at the bias (MIXED packed rows): one add less per value in the epilogue
+      const f32x4 b4 = *(const f32x4*)(p.bias + (3 * chh + j) * 16 + (lane >> 4) * 4);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) oy[a][b][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b) oy[a][b][j][q] = b4;
     }
   // fold the finished position: Y[a][b] += At[a][xi] * At[b][nu] * M,  At = [1 1 1 0; 0 1 -1 -1]; pos compile-time,
   // so only the non-zero terms exist and they are plain adds / subtracts
@@ -304,12 +306,11 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int c0 = (3 * chh + j) * 8 + (q & 1) * 4 + (q >> 1) * 2;
-      const f32x4 bq = *(const f32x4*)(p.bias + (3 * chh + j) * 16 + q * 4);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          const f32x4 v = oy[a][bb][j][tq] + bq;
+          const f32x4 v = oy[a][bb][j][tq];      // (bias already inside)
           const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
           const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
           const float f0 = __uint_as_float(s02[0]), g0 = __uint_as_float(s02[1]);
