@@ -186,20 +186,14 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
     else stage_any(ch, buf);
   };
 
-  // The accumulators start at the bias of their rows (the lane's 4 consecutive rows of each row tile): the epilogue has no
-  // bias add -- every ordinary VALU instruction of an MFMA kernel is paid in MFMA slots.  Row of tile nt:
-  // MIXED: packed row (grp NT + nt) 16 + ...; otherwise features [0, NF) then their gates at nf_full 16 + ...
+  // (Zero-initialised accumulators and a bias add in the epilogue, unlike the raw-tile / Winograd kernels: here the
+  // accumulators' first use sits behind the issue of the NEXT chunk's DMA, and a bias load that hipcc sinks to that point
+  // makes the first MFMA wait for that chunk too -- measured +5.6 % at batch 1, where a workgroup has few chunks.)
   f32x4 acc[NT][PT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int rq = (lane >> 4) * 4;
-    const int brow = MIXED ? (grp * NT + nt) * 16 + rq
-                           : (nt < NT / 2 ? (grp * (NT / 2) + nt) * 16 + rq
-                                          : ((SPLIT ? p.nf_full : NT / 2) + grp * (NT / 2) + (nt - NT / 2)) * 16 + rq);
-    const f32x4 b4 = *(const f32x4*)(p.bias + brow);
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = b4;
-  }
+    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if constexpr (STAGES > 2) {
     // ---- ring of STAGES slots, AHEAD = STAGES - 1 chunks issued before the first MFMA.  Iteration ch: wait until chunk ch
@@ -274,15 +268,23 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
   };
   if (!MIXED) {
     constexpr int NF = NT / 2;       // tiles [0,NF): features, [NF,NT): matching gates
+    const int nff = SPLIT ? p.nf_full : NF;
 #pragma unroll
     for (int nt = 0; nt < NF; ++nt) {
       const int c0 = (grp * NF + nt) * 16 + q * 4;
+      const f32x4 bf = *(const f32x4*)(p.bias + c0);
+      const f32x4 bg = *(const f32x4*)(p.bias + nff * 16 + c0);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
         f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = act_fast(acc[nt][pt][r], eluw) * sigmoid_fast(acc[nt + NF][pt][r]);      // (bias already inside)
+        for (int r = 0; r < 4; ++r) {
+          const float f = acc[nt][pt][r] + bf[r];
+          const float g = acc[nt + NF][pt][r] + bg[r];
+          const float a = act_fast(f, eluw);
+          o[r] = a * sigmoid_fast(g);
+        }
         if (c0 < p.G && pidx < p.total_pix) {
           if (BF16) *(uint2*)((char*)p.dst + (out_off(pidx) + c0) * 2) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
           else *(f32x4*)(p.dst + out_off(pidx) + c0) = o;
@@ -297,10 +299,11 @@ __global__ __launch_bounds__(256, WPS) void gconv_kernel(const GConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int c0 = (grp * NT + nt) * 8 + (q & 1) * 4 + (q >> 1) * 2;
+      const f32x4 bq = *(const f32x4*)(p.bias + (grp * NT + nt) * 16 + q * 4);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int pidx = tile_base + (w * PT + pt) * 16 + (lane & 15);
-        const f32x4 v = acc[nt][pt];                              // (bias already inside)
+        const f32x4 v = acc[nt][pt] + bq;
         const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
         const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
         const float f0 = __uint_as_float(s02[0]), g0 = __uint_as_float(s02[1]);
