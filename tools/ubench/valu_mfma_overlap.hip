@@ -1,7 +1,8 @@
 // Microbenchmark: do VALU / transcendental instructions of one wave overlap with the MFMAs of ANOTHER wave on the same SIMD?
 // A workgroup is 8 waves = 2 per SIMD (wave w runs on SIMD w % 4): waves 0-3 run the "a" loop, waves 4-7 the "b" loop, so each
 // SIMD holds one wave of each kind.  Three launches per pair: a alone (b idle), b alone, both.  both ~ max(a, b): overlap;
-// both ~ a + b: the two share an issue resource.
+// both ~ a + b: the two share an issue resource.  The inline-asm loops (v_add_f32 ... v_permlane32_swap) are latency-bound alone
+// (~7.5 cycles per instruction, 4 of them issue time): read their rows as issue-time accounting -- both ~ mfma + 4 cycles x count.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_mfma_overlap tools/ubench/valu_mfma_overlap.hip && ./valu_mfma_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,7 +10,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { MFMA_BF16 = 0, MFMA_F32 = 1, VALU_FMA = 2, VALU_EXP = 3, VALU_PKFMA = 4, IDLE = 5 };
+enum { MFMA_BF16 = 0, MFMA_F32 = 1, VALU_FMA = 2, VALU_EXP = 3, VALU_PKFMA = 4, IDLE = 5, VALU_MULLO = 6, LDS_READ = 7,
+       OP_ADD_F32 = 10, OP_MUL_F32, OP_MAX_F32, OP_MED3_F32, OP_ADD_U32, OP_AND_B32, OP_CNDMASK, OP_MOV, OP_CVT_PK_BF16, OP_PK_ADD_F32, OP_LSHL_ADD, OP_SWAP };
+#define ASMLOOP(TXT)                                                                  \
+  {                                                                                   \
+    unsigned v[8];                                                                    \
+    for (int i = 0; i < 8; ++i) v[i] = __float_as_uint(in[t][i & 3]) + i;             \
+    unsigned c = __float_as_uint(in[t + 1][0]);                                       \
+    for (int it = 0; it < iters; ++it)                                                \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(TXT : "+v"(v[i]) : "v"(c)); \
+    unsigned s_ = 0;                                                                  \
+    for (int i = 0; i < 8; ++i) s_ += v[i];                                           \
+    return (float)s_;                                                                 \
+  }
 
 template <int KIND>
 __device__ __forceinline__ float work(const f32x4* in, int iters) {
@@ -51,6 +64,50 @@ __device__ __forceinline__ float work(const f32x4* in, int iters) {
     for (int it = 0; it < iters; ++it)
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = __builtin_elementwise_fma(v[i], c, h);
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
+    return s;
+  } else if constexpr (KIND == VALU_MULLO) {
+    unsigned v[8];
+    for (int i = 0; i < 8; ++i) v[i] = __float_as_uint(in[t][i & 3]) + i;
+    const unsigned c = __float_as_uint(in[t + 1][0]) | 1u;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+    unsigned s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i];
+    return (float)s;
+  } else if constexpr (KIND == LDS_READ) {
+    __shared__ __attribute__((aligned(16))) f32x4 buf[512];
+    buf[threadIdx.x] = in[t];
+    __syncthreads();
+    f32x4 acc = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 r;
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((unsigned)(t * 16)), "n"(i * 1024));
+        acc += r;
+      }
+    return acc[0] + acc[1];
+  } else if constexpr (KIND == OP_ADD_F32) ASMLOOP("v_add_f32 %0, %0, %1")
+  else if constexpr (KIND == OP_MUL_F32) ASMLOOP("v_mul_f32 %0, %0, %1")
+  else if constexpr (KIND == OP_MAX_F32) ASMLOOP("v_max_f32 %0, %0, %1")
+  else if constexpr (KIND == OP_MED3_F32) ASMLOOP("v_med3_f32 %0, %0, %1, 0")
+  else if constexpr (KIND == OP_ADD_U32) ASMLOOP("v_add_u32 %0, %0, %1")
+  else if constexpr (KIND == OP_AND_B32) ASMLOOP("v_and_b32 %0, %0, %1")
+  else if constexpr (KIND == OP_CNDMASK) ASMLOOP("v_cndmask_b32 %0, %0, %1, vcc")
+  else if constexpr (KIND == OP_MOV) ASMLOOP("v_mov_b32 %0, %1")
+  else if constexpr (KIND == OP_CVT_PK_BF16) ASMLOOP("v_cvt_pk_bf16_f32 %0, %0, %1")
+  else if constexpr (KIND == OP_LSHL_ADD) ASMLOOP("v_lshl_add_u32 %0, %0, 1, %1")
+  else if constexpr (KIND == OP_SWAP) ASMLOOP("v_permlane32_swap_b32 %0, %1")
+  else if constexpr (KIND == OP_PK_ADD_F32) {
+    f32x2 v[8];
+    for (int i = 0; i < 8; ++i) v[i] = (f32x2){in[t][i & 3] + i, in[t][(i + 1) & 3]};
+    const f32x2 c = {in[t + 1][0], in[t + 1][1]};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
     float s = 0;
     for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
     return s;
@@ -115,5 +172,23 @@ int main() {
   pair<MFMA_F32, VALU_EXP>("mfma 16x16x4 f32", "v_exp_f32", in, out, N, 2 * N);
   pair<VALU_FMA, VALU_EXP>("v_fma_f32", "v_exp_f32", in, out, 4 * N, N);
   pair<MFMA_BF16, MFMA_BF16>("mfma bf16", "mfma bf16", in, out, N, N);
+  pair<MFMA_BF16, VALU_MULLO>("mfma 16x16x32 bf16", "v_mul_lo_u32", in, out, N, N);
+  pair<MFMA_BF16, OP_ADD_F32>("mfma bf16", "v_add_f32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_MUL_F32>("mfma bf16", "v_mul_f32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_MAX_F32>("mfma bf16", "v_max_f32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_MED3_F32>("mfma bf16", "v_med3_f32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_ADD_U32>("mfma bf16", "v_add_u32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_AND_B32>("mfma bf16", "v_and_b32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_CNDMASK>("mfma bf16", "v_cndmask_b32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_MOV>("mfma bf16", "v_mov_b32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_CVT_PK_BF16>("mfma bf16", "v_cvt_pk_bf16_f32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_LSHL_ADD>("mfma bf16", "v_lshl_add_u32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_PK_ADD_F32>("mfma bf16", "v_pk_add_f32", in, out, N, 4 * N);
+  pair<MFMA_BF16, OP_SWAP>("mfma bf16", "v_permlane32_swap", in, out, N, 2 * N);
+  pair<MFMA_F32, OP_ADD_U32>("mfma f32", "v_add_u32", in, out, N, 8 * N);
+  pair<MFMA_F32, OP_PK_ADD_F32>("mfma f32", "v_pk_add_f32", in, out, N, 8 * N);
+  pair<MFMA_F32, VALU_MULLO>("mfma f32", "v_mul_lo_u32", in, out, N, 2 * N);
+  pair<VALU_FMA, VALU_MULLO>("v_fma_f32", "v_mul_lo_u32", in, out, 4 * N, N);
+  pair<VALU_EXP, VALU_MULLO>("v_exp_f32", "v_mul_lo_u32", in, out, N, N);
   return 0;
 }
