@@ -2,7 +2,7 @@
 """Randomised per-layer parity sweep (run on the GPU box): every gated-conv shape of the two networks at random batch /
 height / width (any size, not only multiples of 8: ragged tiles, odd grids that make the Winograd kernels fall back),
 random dilation for the 96 -> 192 shape, fp32 and bf16, default and low-latency launch shapes, against the oracle's
-layer.   usage: python tools/fuzz_ops.py [n_cases] [seed]      (tests/test_gpu_fuzz.py runs 120 cases; 5400 cases at the end of round 2: 0 failures, worst 3.6e-6 fp32; round 3: 7000 cases, 0 failures, 3.9e-6)"""
+layer.   usage: python tools/fuzz_ops.py [n_cases] [seed]      (tests/test_gpu_fuzz.py runs 120 cases; 5400 cases at the end of round 2: 0 failures, worst 3.6e-6 fp32; round 3: 7000 cases, 0 failures, 3.9e-6; final round-3 build: 12000 cases, 0 failures, 3.8e-6 fp32 / 7.8e-3 bf16)"""
 import os
 import sys
 import time
