@@ -111,11 +111,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
   int* Xsrc = Ysrc + 4 * 512;
-  // ... and, beside them, the validity of each row / column as a float (1 inside the image, 0 outside): with the offsets
-  // stored CLAMPED, set_pos is 8 LDS reads, 4 adds and 4 multiplies -- no compare, select or max (round 3: every VALU
-  // instruction of the loop is a lost fp32 MFMA slot)
-  float* Yval = (float*)(Xsrc + 4 * 512);
-  float* Xval = Yval + 4 * 512;
+  // ... and, beside them, the validity of each row / column as a FLAG (0 inside the image, bit 31 outside): set_pos ORs
+  // the flags into the (clamped, < 2^31) byte offset, and the gather goes through a buffer resource whose range check
+  // returns zeros for any offset with bit 31 set -- zero padding costs no arithmetic at all, and the B^T factors that
+  // remain are signs, applied as compile-time +/- in the transform (round 3: every VALU instruction of the loop is a lost
+  // fp32 MFMA slot; this form has 8 LDS reads, 4 adds and 4 ORs per position and 6 packed adds per granule)
+  unsigned* Yval = (unsigned*)(Xsrc + 4 * 512);
+  unsigned* Xval = Yval + 4 * 512;
   const unsigned lane_coff = (unsigned)s_log * 16u;
   int bimg;             // batch index of this lane's tile (address of the per-image vector source)
   {
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       const bool yok = t < p.total_tiles && (unsigned)y < (unsigned)p.h, xok = (unsigned)x < (unsigned)p.w;
       Ysrc[i * 512 + tid] = (int)((unsigned)((b * p.h + (yok ? y : 0)) * p.w) * 384u + lane_coff);
       Xsrc[i * 512 + tid] = xok ? x * 384 : 0;
-      Yval[i * 512 + tid] = yok ? 1.f : 0.f;
-      Xval[i * 512 + tid] = xok ? 1.f : 0.f;
+      Yval[i * 512 + tid] = yok ? 0u : 0x80000000u;
+      Xval[i * 512 + tid] = xok ? 0u : 0x80000000u;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -141,34 +143,51 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   // SIMD partner streams fp32 MFMAs, and inside one wave every VALU instruction is a lost MFMA slot), so the loop
   // keeps the VALU count minimal: gather offsets and transform factors are computed once per POSITION, global
   // loads and the W DMA use scalar base + 32-bit lane offset addressing, LDS addresses are immediates.
-  unsigned o[4];        // byte offsets of the four source pixels of the current position (+ this lane's granule)
-  float g[4];           // their B^T factors (0 for a pixel outside the image: zero padding)
-  auto set_pos = [&](int xi, int nu) {      // xi uniform (loop counter), nu compile-time in the loop
-    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
+  unsigned o[4];        // byte offsets of the four source pixels of the current position (+ this lane's granule); bit 31: outside
+  unsigned ov[4];       // the same for the per-image vector source (NCHK == 6, src1_vec): vec_off | the validity flags
+  const unsigned vec_off = (unsigned)bimg * 384u + lane_coff;     // per-image vector source (NCHK == 6 only)
+  auto set_pos = [&](int xi, int nu) {      // xi, nu compile-time in the unrolled loop
+    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; a pixel outside the image reads as zero
     const int ia = (xi == 0 ? 0 : 1) * 512 + tid, ib = (xi == 3 ? 3 : 2) * 512 + tid;
     const int ja = (nu == 0 ? 0 : 1) * 512 + tid, jb = (nu == 3 ? 3 : 2) * 512 + tid;
     const unsigned ya = Ysrc[ia], yb = Ysrc[ib], xa = Xsrc[ja], xb = Xsrc[jb];
-    // signed validities: the B^T sign is a compile-time negation of a table value (free source modifier)
-    const float sya = xi == 2 ? -Yval[ia] : Yval[ia], syb = (xi == 0 || xi == 3) ? -Yval[ib] : Yval[ib];
-    const float sxa = nu == 2 ? -Xval[ja] : Xval[ja], sxb = (nu == 0 || nu == 3) ? -Xval[jb] : Xval[jb];
-    o[0] = ya + xa; o[1] = ya + xb; o[2] = yb + xa; o[3] = yb + xb;
-    g[0] = sxa * sya; g[1] = sxb * sya; g[2] = sxa * syb; g[3] = sxb * syb;
+    const unsigned fya = Yval[ia], fyb = Yval[ib], fxa = Xval[ja], fxb = Xval[jb];
+    o[0] = (ya + xa) | fya | fxa; o[1] = (ya + xb) | fya | fxb; o[2] = (yb + xa) | fyb | fxa; o[3] = (yb + xb) | fyb | fxb;      // v_add + v_or3
+    if (NCHK == 6 && p.src1_vec) { ov[0] = vec_off | fya | fxa; ov[1] = vec_off | fya | fxb; ov[2] = vec_off | fyb | fxa; ov[3] = vec_off | fyb | fxb; }
   };
-  const unsigned vec_off = (unsigned)bimg * 384u + lane_coff;     // per-image vector source (NCHK == 6 only)
+  // the gathers go through buffer resources: an offset with bit 31 set is out of range and delivers zeros
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NCHK == 6 ? p.src1 : p.src), 0,
+      (int)(NCHK == 6 && p.src1_vec ? (unsigned)p.B * 384u : (unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
   // raw granules of one iteration (chunk = it % NCHK, position already selected by set_pos)
   auto load_x1 = [&](int chunk, f32x4 (&r)[4], int i) {      // granule i (0..3): one vector-memory instruction
     const bool second = NCHK == 6 && chunk >= 3;
-    const char* base = (const char*)(second ? p.src1 : p.src) + (second ? chunk - 3 : chunk) * 128;
-    // spatially constant second source (pooled style vector): one value per image, still zero padded
-    if (second && p.src1_vec) r[i] = *(const f32x4*)(base + (size_t)vec_off);
-    else r[i] = *(const f32x4*)(base + (size_t)o[i]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // (second source: a tensor, or the spatially constant pooled style vector -- one value per image, still zero padded)
+    const u32x4 t = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(p.src1_vec ? ov[i] : o[i]), (chunk - 3) * 128, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o[i], chunk * 128, 0);
+    r[i] = __builtin_bit_cast(f32x4, t);
   };
   auto load_x = [&](int chunk, f32x4 (&r)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_x1(chunk, r, i);
   };
-  auto write_x = [&](int buf, const f32x4 (&r)[4]) {
-    const f32x4 v = r[0] * g[0] + r[1] * g[1] + r[2] * g[2] + r[3] * g[3];
+  // B^T signs of the four granules of position (xi, nu) (compile-time): sy = (a: xi == 2 ? - : +, b: xi == 0 or 3 ? - : +), same in x
+  float negone = -1.f;
+  asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (a plain - becomes 4 v_sub)
+  auto write_x = [&](int buf, const f32x4 (&r)[4], int xi, int nu) {
+    const bool nya = xi == 2, nyb = xi == 0 || xi == 3, nxa = nu == 2, nxb = nu == 0 || nu == 3;
+    const bool n0 = nya != nxa, n1 = nya != nxb, n2 = nyb != nxa, n3 = nyb != nxb;      // granule i enters with a minus sign
+    // sum the + terms and the - terms separately, then one subtraction: at most one packed fma besides the packed adds
+    f32x4 pos = {0.f, 0.f, 0.f, 0.f}, neg = {0.f, 0.f, 0.f, 0.f};
+    bool hp = false, hn = false;
+    const bool ng[4] = {n0, n1, n2, n3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (ng[i]) { neg = hn ? neg + r[i] : r[i]; hn = true; }
+      else { pos = hp ? pos + r[i] : r[i]; hp = true; }
+    }
+    const f32x4 v = !hn ? pos : (!hp ? neg * negone : neg * negone + pos);
     *(f32x4*)(Xb + buf * XB + srow * 128 + ps * 16) = v;
   };
   auto dma_w = [&](int it, int buf, int j) {      // piece j (0..2) of this wave's share of the W tile
@@ -240,8 +259,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
     f32x4 r1[4];                       // chunks 0, 1 of position 0: both loads in flight before the first transform
     load_x(0, r);
     load_x(1, r1);
-    write_x(0, r);
-    write_x(1, r1);
+    write_x(0, r, 0, 0);
+    write_x(1, r1, 0, 0);
   }
   dma_wait_all();
   __syncthreads();
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
       WINO_STAMP(1);
       if (more2) {
         dma_wait_all();                    // granules and W DMA issued in groups 4-7 of the previous iteration
-        write_x(b2, r);
+        write_x(b2, r, ((it + 2) / NCHK) >> 2, ((it + 2) / NCHK) & 3);      // the position of iteration it + 2
       }
       if ((k + 3) % NCHK == 0 && more3)    // position of the granules fetched next
         set_pos(xi + ((k + 3) / NCHK) / 4, ((k + 3) / NCHK) & 3);
