@@ -81,8 +81,11 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
   char* xw0 = Xb + srow * 128 + ((sg ^ swz) << 4);             // k-half 0: logical slot sg
   char* xw1 = Xb + srow * 128 + (((4 + sg) ^ swz) << 4);       // k-half 1: logical slot 4 + sg
   // Source offsets of the 4x4 input tile, kept in LDS (read once per position):
-  //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or -1 if outside / invalid tile
-  //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
+  //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or 0x80000000 if outside / invalid tile
+  //   Xsrc[i][tid] = byte offset of column x_i inside the row, or 0x80000000 if outside
+  // A gather offset is their SATURATING sum (v_add_u32 clamp): >= 2^31 as soon as either part is outside, and the gather
+  // goes through a buffer resource whose range check returns zeros there -- zero padding costs no arithmetic, and the
+  // B^T factors that remain are signs, applied as compile-time +/- in the transform (se_wino.hip).
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);     // 8 * NTHR ints
   int* Xsrc = Ysrc + 4 * NTHR;
   {
@@ -92,41 +95,54 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
-      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : -1;
-      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
+      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : (int)0x80000000;
+      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : (int)0x80000000;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
   int off0, off1;
   frag_offsets(lane, off0, off1);
 
-  unsigned o[2][4];     // [even / odd position of the pair]: byte offsets of the four source pixels
-  float g[2][4];        // their B^T factors (0 for a pixel outside the image: zero padding)
+  unsigned o[2][4];     // [even / odd position of the pair]: byte offsets of the four source pixels (>= 2^31: outside)
   auto set_pos = [&](int set, int pos) {    // compile-time arguments after unrolling
     const int xi = pos >> 2, nu = pos & 3;
-    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; the factor of an outside row / column is 0
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = Ysrc[(xi == 3 ? 3 : 2) * NTHR + tid];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = Xsrc[(nu == 3 ? 3 : 2) * NTHR + tid];
-    const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = yb < 0 ? 0.f : ((xi == 0 || xi == 3) ? -1.f : 1.f);
-    const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = xb < 0 ? 0.f : ((nu == 0 || nu == 3) ? -1.f : 1.f);
-    // always load from a valid (clamped) address; the padding zero is applied through the factor
-    const unsigned ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
-    o[set][0] = ya_c + xa_c; o[set][1] = ya_c + xb_c; o[set][2] = yb_c + xa_c; o[set][3] = yb_c + xb_c;
-    g[set][0] = sxa * sya; g[set][1] = sxb * sya; g[set][2] = sxa * syb; g[set][3] = sxb * syb;
+    // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; a pixel outside the image reads as zero
+    const unsigned ya = (unsigned)Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = (unsigned)Ysrc[(xi == 3 ? 3 : 2) * NTHR + tid];
+    const unsigned xa = (unsigned)Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = (unsigned)Xsrc[(nu == 3 ? 3 : 2) * NTHR + tid];
+    o[set][0] = __builtin_elementwise_add_sat(ya, xa); o[set][1] = __builtin_elementwise_add_sat(ya, xb);
+    o[set][2] = __builtin_elementwise_add_sat(yb, xa); o[set][3] = __builtin_elementwise_add_sat(yb, xb);
   };
   // k-half h of iteration it -> (position set, 16-channel group): see the chunk table in the header
   auto half_set = [](int it, int h) { return (it % 3) * 2 + h >= 3 ? 1 : 0; };
   auto half_grp = [](int it, int h) { return ((it % 3) * 2 + h) % 3; };
+  // position whose granules k-half h of iteration `it` carries: pair it / 3, even or odd member
+  auto half_pos = [&](int it, int h) { return 2 * (it / 3) + half_set(it, h); };
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 192u), 0x00020000);
   // one raw granule (pixel i of the 4 sources) of k-half h of iteration `it`: one vector-memory instruction
   auto load_x1 = [&](int it, f32x4 (&r)[2][4], int h, int i) {
-    r[h][i] = *(const f32x4*)((const char*)p.src + half_grp(it, h) * 64 + (size_t)o[half_set(it, h)][i]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o[half_set(it, h)][i], half_grp(it, h) * 64, 0);
+    r[h][i] = __builtin_bit_cast(f32x4, t);
+  };
+  float negone = -1.f;
+  asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (a plain - becomes 4 v_sub)
+  // the four granules of position (xi, nu) combined with their B^T signs (compile-time)
+  auto signed_sum = [&](const f32x4 (&q)[4], int pos) -> f32x4 {
+    const int xi = pos >> 2, nu = pos & 3;
+    const bool nya = xi == 2, nyb = xi == 0 || xi == 3, nxa = nu == 2, nxb = nu == 0 || nu == 3;
+    const bool ng[4] = {nya != nxa, nya != nxb, nyb != nxa, nyb != nxb};      // granule i enters with a minus sign
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f}, ns = {0.f, 0.f, 0.f, 0.f};
+    bool hp = false, hn = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (ng[i]) { ns = hn ? ns + q[i] : q[i]; hn = true; }
+      else { ps = hp ? ps + q[i] : q[i]; hp = true; }
+    }
+    return !hn ? ps : (!hp ? ns * negone : ns * negone + ps);
   };
   auto write_x = [&](int it, int buf, const f32x4 (&r)[2][4]) {
-    const int s0 = half_set(it, 0), s1 = half_set(it, 1);
-    const f32x4 v0 = r[0][0] * g[s0][0] + r[0][1] * g[s0][1] + r[0][2] * g[s0][2] + r[0][3] * g[s0][3];
-    const f32x4 v1 = r[1][0] * g[s1][0] + r[1][1] * g[s1][1] + r[1][2] * g[s1][2] + r[1][3] * g[s1][3];
-    *(f32x4*)(xw0 + buf * XB) = v0;
-    *(f32x4*)(xw1 + buf * XB) = v1;
+    *(f32x4*)(xw0 + buf * XB) = signed_sum(r[0], half_pos(it, 0));
+    *(f32x4*)(xw1 + buf * XB) = signed_sum(r[1], half_pos(it, 1));
   };
   // W tile: 12 row blocks of 8 rows; wave w stages blocks w, w + NWV, ... (8 waves: 2 calls, 4 waves: 3 calls per tile)
   auto dma_w = [&](int it, int buf, int j) {
