@@ -52,8 +52,10 @@ __global__ __launch_bounds__(TILES * 4, 2) void winoup_kernel(const WinoParams p
   char* xw0 = Xb + srow * 128 + ((sg ^ swz) << 4);             // k-half 0: logical slot sg
   char* xw1 = Xb + srow * 128 + (((4 + sg) ^ swz) << 4);       // k-half 1: logical slot 4 + sg
   // Source offsets of the 3x3 input tile, kept in LDS (read once per position):
-  //   Ysrc[i][tid] = byte offset of source row yy0 - 1 + py + i (+ this lane's granule), or -1 if outside / invalid tile
-  //   Xsrc[i][tid] = byte offset of source column xx0 - 1 + px + i inside the row, or -1 if outside
+  //   Ysrc[i][tid] = byte offset of source row yy0 - 1 + py + i (+ this lane's granule), or 0x80000000 if outside / invalid tile
+  //   Xsrc[i][tid] = byte offset of source column xx0 - 1 + px + i inside the row, or 0x80000000 if outside
+  // A gather offset is their saturating sum; the gather goes through a buffer resource (>= 2^31: zeros), the B^T factors
+  // that remain are compile-time signs (se_wino.hip, se_wino48.hip).
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
   int* Xsrc = Ysrc + 3 * NTHR;
   {
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(TILES * 4, 2) void winoup_kernel(const WinoParams p
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int y = y0 - 1 + py + i, x = x0 - 1 + px + i;
-      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + (unsigned)sg * 16u) : -1;
-      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 384 : -1;
+      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + (unsigned)sg * 16u) : (int)0x80000000;
+      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 384 : (int)0x80000000;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -74,30 +76,40 @@ __global__ __launch_bounds__(TILES * 4, 2) void winoup_kernel(const WinoParams p
   // B^T rows: xi=0: +d0 -d1 | 1: +d1 | 2: -d1 +d2.  Source pixel i of a position = (row a|b, column a|b):
   // i=0 (a,a), 1 (a,b), 2 (b,a), 3 (b,b); the b row (column) does not exist for xi == 1 (nu == 1).
   auto need = [](int pos, int i) { return !((pos / 3 == 1 && i >= 2) || (pos % 3 == 1 && (i & 1))); };
-  unsigned o[4];        // byte offsets of the source pixels of the current position (+ this lane's granule)
-  float g[4];           // their B^T factors (0 for a pixel outside the image: zero padding)
+  unsigned o[4];        // byte offsets of the source pixels of the current position (+ this lane's granule); >= 2^31: outside
   auto set_pos = [&](int pos) {             // compile-time argument after unrolling
     const int xi = pos / 3, nu = pos % 3;
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = Ysrc[(xi == 2 ? 2 : 1) * NTHR + tid];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = Xsrc[(nu == 2 ? 2 : 1) * NTHR + tid];
-    const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = (xi == 1 || yb < 0) ? 0.f : (xi == 0 ? -1.f : 1.f);
-    const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = (nu == 1 || xb < 0) ? 0.f : (nu == 0 ? -1.f : 1.f);
-    // always load from a valid (clamped) address; the padding zero is applied through the factor
-    const unsigned ya_c = max(ya, 0), yb_c = max(yb, 0), xa_c = max(xa, 0), xb_c = max(xb, 0);
-    o[0] = ya_c + xa_c; o[1] = ya_c + xb_c; o[2] = yb_c + xa_c; o[3] = yb_c + xb_c;
-    g[0] = sxa * sya; g[1] = sxb * sya; g[2] = sxa * syb; g[3] = sxb * syb;
+    const unsigned ya = (unsigned)Ysrc[(xi == 0 ? 0 : 1) * NTHR + tid], yb = (unsigned)Ysrc[(xi == 2 ? 2 : 1) * NTHR + tid];
+    const unsigned xa = (unsigned)Xsrc[(nu == 0 ? 0 : 1) * NTHR + tid], xb = (unsigned)Xsrc[(nu == 2 ? 2 : 1) * NTHR + tid];
+    o[0] = __builtin_elementwise_add_sat(ya, xa); o[1] = __builtin_elementwise_add_sat(ya, xb);
+    o[2] = __builtin_elementwise_add_sat(yb, xa); o[3] = __builtin_elementwise_add_sat(yb, xb);
   };
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
   // one raw granule (source pixel i) of k-half h of iteration `it` (position it/3, channels (it%3)*32 + h*16 ...)
   auto load_x1 = [&](int it, f32x4 (&r)[2][4], int h, int i) {
-    if (need(it / 3, i)) r[h][i] = *(const f32x4*)((const char*)p.src + ((it % 3) * 32 + h * 16) * 4 + (size_t)o[i]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if (need(it / 3, i)) r[h][i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o[i], ((it % 3) * 32 + h * 16) * 4, 0));
+  };
+  float negone = -1.f;
+  asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (a plain - becomes 4 v_sub)
+  // the granules of a position combined with their B^T signs: row a: xi == 2 ? - : +, row b: xi == 0 ? - : +, same in x
+  auto signed_sum = [&](const f32x4 (&q)[4], int pos) -> f32x4 {
+    const int xi = pos / 3, nu = pos % 3;
+    const bool nya = xi == 2, nyb = xi == 0, nxa = nu == 2, nxb = nu == 0;
+    const bool ng[4] = {nya != nxa, nya != nxb, nyb != nxa, nyb != nxb};
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f}, ns = {0.f, 0.f, 0.f, 0.f};
+    bool hp = false, hn = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!need(pos, i)) continue;
+      if (ng[i]) { ns = hn ? ns + q[i] : q[i]; hn = true; }
+      else { ps = hp ? ps + q[i] : q[i]; hp = true; }
+    }
+    return !hn ? ps : (!hp ? ns * negone : ns * negone + ps);
   };
   auto write_x = [&](int it, int buf, const f32x4 (&r)[2][4]) {
-    f32x4 v0 = r[0][0] * g[0], v1 = r[1][0] * g[0];
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-      if (need(it / 3, i)) { v0 = r[0][i] * g[i] + v0; v1 = r[1][i] * g[i] + v1; }
-    *(f32x4*)(xw0 + buf * XB) = v0;
-    *(f32x4*)(xw1 + buf * XB) = v1;
+    *(f32x4*)(xw0 + buf * XB) = signed_sum(r[0], it / 3);
+    *(f32x4*)(xw1 + buf * XB) = signed_sum(r[1], it / 3);
   };
   // W tile: 12 row blocks of 8 rows; wave w stages block w, and block 8 + w if w < 4
   auto dma_w = [&](int it, int buf, int j) {
