@@ -53,7 +53,7 @@ extern "C" int se_debug_wino_trace(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_trace), sizeof(unsigned long long) * 96 * 8);
 }
 // stamps go to LDS (a global store per stamp would sit in vmcnt and distort the waits being measured)
-#define WINO_TRACE_LDS (3 * 64 * 128 + 4 * 192 * 128 + 16 * 512 * 4)
+#define WINO_TRACE_LDS (3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4)
 #define WINO_STAMP(k)                                                   \
   do {                                                                  \
     if (blockIdx.x == 0 && (w & 3) == 0) {                              \
@@ -107,17 +107,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   const int srow = tid >> 3, ps = tid & 7;
   const int s_log = ps ^ ((srow >> 1) & 7);
   // Source offsets of the 4x4 input tile, kept in LDS (read once per position; registers are the scarce resource):
-  //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or -1 if outside / invalid tile
-  //   Xsrc[i][tid] = byte offset of column x_i inside the row, or -1 if outside
+  //   Ysrc[i][tid] = byte offset of pixel row y_i (+ this lane's granule), or 0x80000000 if outside / invalid tile
+  //   Xsrc[i][tid] = byte offset of column x_i inside the row, or 0x80000000 if outside
+  // A gather offset is their SATURATING sum (v_add_u32 clamp): >= 2^31 as soon as either part is outside (valid sums stay
+  // below 2^31: the launch guards the tensor's bytes), and the gather goes through a buffer resource whose range check
+  // returns zeros there -- zero padding costs no arithmetic at all, and the B^T factors that remain are signs, applied as
+  // compile-time +/- in the transform.  set_pos is 4 LDS reads and 4 adds; the transform 8 instructions per granule
+  // (round 3: every VALU instruction of the loop is a lost fp32 MFMA slot; the first form had 8 reads, 4 adds, 4
+  // multiplies per position and 4 multiplies + 6 packed fmas per granule).
   int* Ysrc = (int*)(smem + 3 * XB + 4 * WB);
   int* Xsrc = Ysrc + 4 * 512;
-  // ... and, beside them, the validity of each row / column as a FLAG (0 inside the image, bit 31 outside): set_pos ORs
-  // the flags into the (clamped, < 2^31) byte offset, and the gather goes through a buffer resource whose range check
-  // returns zeros for any offset with bit 31 set -- zero padding costs no arithmetic at all, and the B^T factors that
-  // remain are signs, applied as compile-time +/- in the transform (round 3: every VALU instruction of the loop is a lost
-  // fp32 MFMA slot; this form has 8 LDS reads, 4 adds and 4 ORs per position and 6 packed adds per granule)
-  unsigned* Yval = (unsigned*)(Xsrc + 4 * 512);
-  unsigned* Xval = Yval + 4 * 512;
   const unsigned lane_coff = (unsigned)s_log * 16u;
   int bimg;             // batch index of this lane's tile (address of the per-image vector source)
   {
@@ -129,10 +128,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
       const bool yok = t < p.total_tiles && (unsigned)y < (unsigned)p.h, xok = (unsigned)x < (unsigned)p.w;
-      Ysrc[i * 512 + tid] = (int)((unsigned)((b * p.h + (yok ? y : 0)) * p.w) * 384u + lane_coff);
-      Xsrc[i * 512 + tid] = xok ? x * 384 : 0;
-      Yval[i * 512 + tid] = yok ? 0u : 0x80000000u;
-      Xval[i * 512 + tid] = xok ? 0u : 0x80000000u;
+      Ysrc[i * 512 + tid] = yok ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + lane_coff) : (int)0x80000000;
+      Xsrc[i * 512 + tid] = xok ? x * 384 : (int)0x80000000;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -143,17 +140,20 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   // SIMD partner streams fp32 MFMAs, and inside one wave every VALU instruction is a lost MFMA slot), so the loop
   // keeps the VALU count minimal: gather offsets and transform factors are computed once per POSITION, global
   // loads and the W DMA use scalar base + 32-bit lane offset addressing, LDS addresses are immediates.
-  unsigned o[4];        // byte offsets of the four source pixels of the current position (+ this lane's granule); bit 31: outside
+  unsigned o[4];        // byte offsets of the four source pixels of the current position (+ this lane's granule); >= 2^31: outside
   unsigned ov[4];       // the same for the per-image vector source (NCHK == 6, src1_vec): vec_off | the validity flags
   const unsigned vec_off = (unsigned)bimg * 384u + lane_coff;     // per-image vector source (NCHK == 6 only)
   auto set_pos = [&](int xi, int nu) {      // xi, nu compile-time in the unrolled loop
     // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; a pixel outside the image reads as zero
     const int ia = (xi == 0 ? 0 : 1) * 512 + tid, ib = (xi == 3 ? 3 : 2) * 512 + tid;
     const int ja = (nu == 0 ? 0 : 1) * 512 + tid, jb = (nu == 3 ? 3 : 2) * 512 + tid;
-    const unsigned ya = Ysrc[ia], yb = Ysrc[ib], xa = Xsrc[ja], xb = Xsrc[jb];
-    const unsigned fya = Yval[ia], fyb = Yval[ib], fxa = Xval[ja], fxb = Xval[jb];
-    o[0] = (ya + xa) | fya | fxa; o[1] = (ya + xb) | fya | fxb; o[2] = (yb + xa) | fyb | fxa; o[3] = (yb + xb) | fyb | fxb;      // v_add + v_or3
-    if (NCHK == 6 && p.src1_vec) { ov[0] = vec_off | fya | fxa; ov[1] = vec_off | fya | fxb; ov[2] = vec_off | fyb | fxa; ov[3] = vec_off | fyb | fxb; }
+    const unsigned ya = (unsigned)Ysrc[ia], yb = (unsigned)Ysrc[ib], xa = (unsigned)Xsrc[ja], xb = (unsigned)Xsrc[jb];
+    o[0] = __builtin_elementwise_add_sat(ya, xa); o[1] = __builtin_elementwise_add_sat(ya, xb);
+    o[2] = __builtin_elementwise_add_sat(yb, xa); o[3] = __builtin_elementwise_add_sat(yb, xb);
+    if (NCHK == 6 && p.src1_vec) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ov[i] = vec_off | (o[i] & 0x80000000u);      // v_and_or_b32
+    }
   };
   // the gathers go through buffer resources: an offset with bit 31 set is out of range and delivers zeros
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 
 template <int NCHK>
 static hipError_t launch_wino_t(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 64 * 128 + 4 * 192 * 128 + 16 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 24 KB + W ring 96 KB + source offsets / validities 32 KB
+  constexpr int LDS = 3 * 64 * 128 + 4 * 192 * 128 + 8 * 512 * 4 + (WINO_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring 24 KB + W ring 96 KB + source offsets 16 KB
   {
     hipError_t e = ensure_max_lds((const void*)wino_kernel<NCHK>, LDS);
     if (e != hipSuccess) return e;
