@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256, 3) void winoup48_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int y = y0 - 1 + py + i, x = x0 - 1 + px + i;
-      Ysrc[i * TILES + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u) : -1;
-      Xsrc[i * TILES + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : -1;
+      Ysrc[i * TILES + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u) : (int)0x80000000;
+      Xsrc[i * TILES + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : (int)0x80000000;
     }
   }
   __syncthreads();
@@ -84,41 +84,51 @@ __global__ __launch_bounds__(256, 3) void winoup48_kernel(const WinoParams p) {
     const int pc = pos < NPOS ? pos : NPOS - 1;
     return !((pc / 3 == 1 && i >= 2) || (pc % 3 == 1 && (i & 1)));
   };
-  unsigned o[2][4];     // [even / odd position of the pair]: byte offsets of the source pixels (+ this lane's granule)
-  float g[2][4];        // their B^T factors (0 for a pixel outside the image: zero padding)
+  unsigned o[2][4];     // [even / odd position of the pair]: byte offsets of the source pixels (+ this lane's granule); >= 2^31: outside
   auto set_pos = [&](int set, int pos) {    // compile-time arguments after unrolling
     const int pc = pos < NPOS ? pos : NPOS - 1;
     const int xi = pc / 3, nu = pc % 3;
-    const int ya = Ysrc[(xi == 0 ? 0 : 1) * TILES + srow], yb = Ysrc[(xi == 2 ? 2 : 1) * TILES + srow];
-    const int xa = Xsrc[(nu == 0 ? 0 : 1) * TILES + srow], xb = Xsrc[(nu == 2 ? 2 : 1) * TILES + srow];
-    const float sya = ya < 0 ? 0.f : (xi == 2 ? -1.f : 1.f), syb = (xi == 1 || yb < 0) ? 0.f : (xi == 0 ? -1.f : 1.f);
-    const float sxa = xa < 0 ? 0.f : (nu == 2 ? -1.f : 1.f), sxb = (nu == 1 || xb < 0) ? 0.f : (nu == 0 ? -1.f : 1.f);
-    // always load from a valid (clamped) address; the padding zero is applied through the factor
-    const unsigned ya_c = max(ya, 0) + sg16, yb_c = max(yb, 0) + sg16, xa_c = max(xa, 0), xb_c = max(xb, 0);
-    o[set][0] = ya_c + xa_c; o[set][1] = ya_c + xb_c; o[set][2] = yb_c + xa_c; o[set][3] = yb_c + xb_c;
-    g[set][0] = sxa * sya; g[set][1] = sxb * sya; g[set][2] = sxa * syb; g[set][3] = sxb * syb;
+    const unsigned ya = (unsigned)Ysrc[(xi == 0 ? 0 : 1) * TILES + srow] + sg16, yb = (unsigned)Ysrc[(xi == 2 ? 2 : 1) * TILES + srow] + sg16;
+    const unsigned xa = (unsigned)Xsrc[(nu == 0 ? 0 : 1) * TILES + srow], xb = (unsigned)Xsrc[(nu == 2 ? 2 : 1) * TILES + srow];
+    o[set][0] = __builtin_elementwise_add_sat(ya, xa); o[set][1] = __builtin_elementwise_add_sat(ya, xb);
+    o[set][2] = __builtin_elementwise_add_sat(yb, xa); o[set][3] = __builtin_elementwise_add_sat(yb, xb);
   };
   // k-half h of iteration it -> (position set, 16-channel group, position): the chunk table in the header
   auto half_set = [](int it, int h) { return (it % 3) * 2 + h >= 3 ? 1 : 0; };
   auto half_grp = [](int it, int h) { return ((it % 3) * 2 + h) % 3; };
   auto half_pos = [&](int it, int h) { return 2 * (it / 3) + half_set(it, h); };
+  // (components pinned to SGPRs: left alone hipcc keeps this resource in VGPRs here and wraps every gather in a
+  // v_readfirstlane waterfall loop -- 309 of them)
+  const unsigned long long src_a = (unsigned long long)p.src;
+  const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)src_a), src_hi = __builtin_amdgcn_readfirstlane((unsigned)(src_a >> 32));
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)src_hi << 32) | src_lo), 0,
+      __builtin_amdgcn_readfirstlane((int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 192u)), 0x00020000);
   // one raw granule (source pixel i) of k-half h of iteration `it`: one vector-memory instruction
   auto load_x1 = [&](int it, f32x4 (&r)[2][4], int h, int i) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     if (need(half_pos(it, h), i))
-      r[h][i] = *(const f32x4*)((const char*)p.src + half_grp(it, h) * 64 + (size_t)o[half_set(it, h)][i]);
+      r[h][i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o[half_set(it, h)][i], half_grp(it, h) * 64, 0));
+  };
+  float negone = -1.f;
+  asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (a plain - becomes 4 v_sub)
+  auto signed_sum = [&](const f32x4 (&q)[4], int pos) -> f32x4 {
+    const int pc = pos < NPOS ? pos : NPOS - 1;
+    const int xi = pc / 3, nu = pc % 3;
+    const bool nya = xi == 2, nyb = xi == 0, nxa = nu == 2, nxb = nu == 0;
+    const bool ng[4] = {nya != nxa, nya != nxb, nyb != nxa, nyb != nxb};
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f}, ns = {0.f, 0.f, 0.f, 0.f};
+    bool hp = false, hn = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!need(pos, i)) continue;
+      if (ng[i]) { ns = hn ? ns + q[i] : q[i]; hn = true; }
+      else { ps = hp ? ps + q[i] : q[i]; hp = true; }
+    }
+    return !hn ? ps : (!hp ? ns * negone : ns * negone + ps);
   };
   auto write_x = [&](int it, int buf, const f32x4 (&r)[2][4]) {
-    f32x4 v[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int s = half_set(it, h), pos = half_pos(it, h);
-      v[h] = r[h][0] * g[s][0];
-#pragma unroll
-      for (int i = 1; i < 4; ++i)
-        if (need(pos, i)) v[h] = r[h][i] * g[s][i] + v[h];
-    }
-    *(f32x4*)(xw0 + buf * XB) = v[0];
-    *(f32x4*)(xw1 + buf * XB) = v[1];
+    *(f32x4*)(xw0 + buf * XB) = signed_sum(r[0], half_pos(it, 0));
+    *(f32x4*)(xw1 + buf * XB) = signed_sum(r[1], half_pos(it, 1));
   };
   // W tile: 6 row blocks of 8 rows; wave w stages block w, and block 4 + w if w < 2
   auto dma_w = [&](int it, int buf, int j) {
