@@ -364,6 +364,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
   if (t < p.total_tiles) {
     int b, y0, x0;
     tile_origin(t, b, y0, x0);
+    // one 32-bit byte offset per lane (the launch guards the tensor's bytes below 2^31) + wave-uniform increments from a
+    // scalar base: the stores need no 64-bit address arithmetic (v_mad_u64_u32 is quarter rate)
+    const unsigned dst0 = (unsigned)((b * p.h + y0) * p.w + x0) * 384u + (unsigned)(3 * chh * 16 + q * 4) * 4u;
+    const unsigned dinc_y = (unsigned)(p.d * p.w) * 384u, dinc_x = (unsigned)p.d * 384u;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int c0 = (3 * chh + j) * 16 + q * 4;
@@ -375,14 +379,14 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
           if (p.vbias) {      // folded vector source (launch_vecbias): a bias that depends on the pixel's border configuration
             const int y = y0 + a * p.d, x = x0 + bb * p.d;
             const int cfg = 3 * (y == 0 ? 0 : (y == p.h - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.w - 1 ? 2 : 1));
-            const float* tb = p.vbias + ((size_t)b * 9 + cfg) * 192 + c0;
+            const float* tb = (const float*)((const char*)p.vbias + (unsigned)(((b * 9 + cfg) * 192 + c0) * 4));
             vf += *(const f32x4*)tb;
             vg += *(const f32x4*)(tb + 96);
           }
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = act_fast(vf[e], eluw) * sigmoid_fast(vg[e]);
-          *(f32x4*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 96 + c0) = o;
+          *(f32x4*)((char*)p.dst + (dst0 + (unsigned)(j * 64) + (a ? dinc_y : 0u) + (bb ? dinc_x : 0u))) = o;
         }
     }
   }
