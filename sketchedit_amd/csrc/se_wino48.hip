@@ -335,7 +335,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
           ov.x = act_fast(f0, eluw) * sigmoid_fast(g0);
           ov.y = act_fast(f1, eluw) * sigmoid_fast(g1);
           if (t < p.total_tiles)
-            *(float2*)(p.dst + ((size_t)(b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 48 + c0) = ov;
+            *(float2*)((char*)p.dst + ((unsigned)((b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 192u + (unsigned)c0 * 4u)) = ov;      // 32-bit offset: the launch guards the bytes
         }
     }
   }

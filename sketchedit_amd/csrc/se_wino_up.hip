@@ -273,7 +273,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void winoup_kernel(const WinoParams p
           ov.x = act_fast(f0, eluw) * sigmoid_fast(g0);
           ov.y = act_fast(f1, eluw) * sigmoid_fast(g1);
           if (t < p.total_tiles)
-            *(float2*)(p.dst + ((size_t)(b * 2 * p.h + 2 * (y0 + a) + py) * OW + 2 * (x0 + bb) + px) * 48 + c0) = ov;
+            *(float2*)((char*)p.dst + ((unsigned)((b * 2 * p.h + 2 * (y0 + a) + py) * OW + 2 * (x0 + bb) + px) * 192u + (unsigned)c0 * 4u)) = ov;      // 32-bit offset (output bytes < 2^32: twice the guarded input bytes)
         }
     }
   }

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void winoup48_kernel(const WinoParams p) {
           ov.x = act_fast(f0, eluw) * sigmoid_fast(g0);
           ov.y = act_fast(f1, eluw) * sigmoid_fast(g1);
           if (t < p.total_tiles)
-            *(float2*)(p.dst + ((size_t)(b * 2 * p.h + 2 * (y0 + a) + py) * OW + 2 * (x0 + bb) + px) * 24 + c0) = ov;
+            *(float2*)((char*)p.dst + ((unsigned)((b * 2 * p.h + 2 * (y0 + a) + py) * OW + 2 * (x0 + bb) + px) * 96u + (unsigned)c0 * 4u)) = ov;      // 32-bit offset: the launch guards the output bytes
         }
     }
   }
