@@ -237,21 +237,29 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   };
   // ---- prologue: weight step 0, the raw tile, weight step 1 (in this order: the loop's counted waits rely on it)
   dma_w(0, 0); dma_w(0, 1); dma_w(0, 2);
+  // The raw tile, one ROW (18 pixels x 12 granules = 216 slots = 4 instructions of 54 lanes) at a time: wave w issues
+  // quarter w of every row, so which column and granule a lane fetches is a per-lane constant and the row is wave-uniform
+  // (scalar arithmetic).  Two VALU instructions per DMA instead of ~35 (slot -> pixel -> row / column divisions for each
+  // of the flat 64-slot pieces): the address arithmetic was a tenth of the issue time of this kernel's MFMAs, and ordinary
+  // VALU instructions exclude MFMAs on the SIMD.  Same LDS image: slot s of row r at r * 3456 + 16 s.
+  {
+    const int sl = 54 * w + lane;                    // this lane's slot of a row (lane < 54)
+    const int c = (sl * 5462) >> 16, gs = sl - c * 12;      // sl / 12 (sl < 216)
+    const int gl = gs ^ (((c >> 2) & 1) << 1);       // stored slot gs holds logical granule gl (layout note at the top)
+    const int second = dual && c >= 10;              // (dual: c = 9 gives sx = 8 = ws, the shared zero column)
+    const int sx = dual ? (second ? c - 10 : c - 1) : tx0 - 1 + c;
+    const bool colok = lane < 54 && (unsigned)sx < (unsigned)p.ws;
+    const unsigned coloff = (unsigned)(sx * p.d + second) * 192u + (unsigned)gl * 16u;
 #pragma unroll
-  for (int i0 = 0; i0 < (NDMA + 3) / 4; ++i0) {
-    const int i = i0 * 4 + w;
-    if (i < NDMA) {
-      const int q = i * 64 + lane;                   // granule slot of the raw tile
-      const int pix = q / 12, gs = q - pix * 12;
-      const int row = pix / RSX, c = pix - row * RSX;
-      const int gl = gs ^ (((c >> 2) & 1) << 1);     // stored slot gs holds logical granule gl (layout note at the top)
-      const int sy = ty0 - 1 + row;
-      const int second = dual && c >= 10;             // (dual: c = 9 gives sx = 8 = ws, the shared zero column)
-      const int sx = dual ? (second ? c - 10 : c - 1) : tx0 - 1 + c;
-      const bool ok = q < RSY * RSX * 12 && (unsigned)sy < (unsigned)p.hs && (unsigned)sx < (unsigned)p.ws;
-      const unsigned off = (unsigned)((b * p.h + sy * p.d + py) * p.w + sx * p.d + px + second) * 192u + (unsigned)gl * 16u;
-      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);
+    for (int row = 0; row < RSY; ++row) {
+      const int sy = ty0 - 1 + row;                                            // wave-uniform from here ...
+      const bool rowok = (unsigned)sy < (unsigned)p.hs;
+      const unsigned rowbase = (unsigned)((b * p.h + sy * p.d + py) * p.w + px) * 192u;
+      const unsigned off = (rowok && colok) ? rowbase + coloff : 0x80000000u;   // ... to here: one add, one select
+      if (lane < 54) bufdma16(off, rsrc, lds_raw + row * (RSX * 192) + w * 864);
     }
+    // the slack behind the last row ("column 18" of row 9 in the dual-phase layout) must read as zeros
+    if (w == 0 && lane < (RAWB - RSY * RSX * 192) / 16) bufdma16(0x80000000u, rsrc, lds_raw + RSY * RSX * 192);
   }
   dma_w(1, 0); dma_w(1, 1); dma_w(1, 2);
 
