@@ -67,20 +67,33 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
   };
   // ---- prologue: weight step 0, the raw tile, weight step 1 (in this order: the counted waits rely on it)
   dma_w(0, 0); dma_w(0, 1);
+  // The raw tile row by row (se_rconv16.hip): a row is RSP * P slots = NI instructions of LPI lanes, wave w issues piece
+  // w % NI of the rows w / NI, w / NI + 4 / NI, ...: column and granule are per-lane constants, the row arithmetic is scalar,
+  // two VALU instructions per DMA instead of ~35.  Same LDS image: slot s of row r at r * ROWB + 16 s.
+  {
+    constexpr int ROWSLOTS = RSP * P, NI = (ROWSLOTS + 63) / 64, LPI = ROWSLOTS / NI;
+    static_assert(NI * LPI == ROWSLOTS && (NI == 1 || NI == 2 || NI == 4), "row pieces");
+    const int kp = w % NI, r0 = w / NI;
+    const int sl = LPI * kp + lane;                                  // this lane's slot of a row (lane < LPI)
+    const int cs = sl / P, gs = sl - cs * P;                         // stored column, stored slot (compile-time divisor)
+    const int c = STRIDE == 2 ? 2 * (cs % HALF) + cs / HALF : cs;    // source column of the tile (parity planes)
+    const int gl = CG == 12 ? gs ^ (((c >> 2) & 1) << 1) : gs;       // stored slot gs holds logical granule gl
+    const int sx = STRIDE * tx0 - padx + c;
+    const bool colok = lane < LPI && gs < CG && c < RS && (unsigned)sx < (unsigned)p.w;
+    const unsigned coloff = (unsigned)sx * (unsigned)(CG * 16) + (unsigned)gl * 16u;
 #pragma unroll
-  for (int i0 = 0; i0 < (NDMA + 3) / 4; ++i0) {
-    const int i = i0 * 4 + w;
-    if (i < NDMA) {
-      const int q = i * 64 + lane;                   // granule slot of the raw tile
-      const int pix = q / P, gs = q - pix * P;
-      const int row = pix / RSP, cs = pix - row * RSP;               // stored column
-      const int c = STRIDE == 2 ? 2 * (cs % HALF) + cs / HALF : cs;    // source column of the tile (parity planes)
-      const int gl = CG == 12 ? gs ^ (((c >> 2) & 1) << 1) : gs;     // stored slot gs holds logical granule gl
-      const int sy = STRIDE * ty0 - pady + row, sx = STRIDE * tx0 - padx + c;
-      const bool ok = q < SLOTS && gs < CG && c < RS && (unsigned)sy < (unsigned)p.h && (unsigned)sx < (unsigned)p.w;
-      const unsigned off = (unsigned)((b * p.h + sy) * p.w + sx) * (unsigned)(CG * 16) + (unsigned)gl * 16u;
-      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);      // outside the image / pad granule: zero fill
+    for (int i = 0; i < (RS * NI + 3) / 4; ++i) {
+      const int row = r0 + i * (4 / NI);                             // wave-uniform from here ...
+      if (row < RS) {
+        const int sy = STRIDE * ty0 - pady + row;
+        const bool rowok = (unsigned)sy < (unsigned)p.h;
+        const unsigned rowbase = (unsigned)((b * p.h + sy) * p.w) * (unsigned)(CG * 16);
+        const unsigned off = (rowok && colok) ? rowbase + coloff : 0x80000000u;      // ... to here: one add, one select
+        if (lane < LPI) bufdma16(off, rsrc, lds_raw + row * ROWB + kp * (LPI * 16));   // outside the image / pad granule: zero fill
+      }
     }
+    // the slack behind the last row is never multiplied by a non-zero weight, but must not hold NaN bit patterns
+    if (w == 0 && lane < (RAWB - RS * ROWB) / 16) bufdma16(0x80000000u, rsrc, lds_raw + RS * ROWB);
   }
   if (NSTEP > 1) { dma_w(1, 0); dma_w(1, 1); }
 
