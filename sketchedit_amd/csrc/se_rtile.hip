@@ -57,15 +57,43 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
     const int npieces = p.nch * p.NP / 8;    // 1 KB pieces (8 rows of 128 bytes)
     for (int i = w; i < npieces; i += 4) glds16_s(wsrc + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
     const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.Hin * p.Win * (unsigned)pixb);
+    // The raw tile in groups of G whole rows (G = 1, or as many rows as fit 64 lanes when a row is short): a group is NI
+    // pieces of LPI lanes, wave w issues piece w % NI of the groups w / NI, w / NI + 4 / NI, ...  Which row of the group,
+    // column and granule a lane fetches is a per-lane constant (the two divisions below run once, not once per 64 slots),
+    // the group's row arithmetic is scalar: ~7 VALU instructions per DMA instead of ~40.  The address arithmetic was up to
+    // as much issue time as the layer's MFMAs (48 -> 48 upsampling in bf16), and ordinary VALU instructions exclude MFMAs
+    // on the SIMD.  Same LDS image: slot s of row r at (r * RW * cgp + s) * 16.
     const int slots = p.RH * p.RW * cgp;
-    for (int i = w; i * 64 < slots; i += 4) {
-      const int q = i * 64 + lane;
-      const int pix = (int)udiv_magic((unsigned)q, p.div_cg_m, p.div_cg_l), gs = q - pix * cgp;
-      const int row = (int)udiv_magic((unsigned)pix, p.div_rw_m, p.div_rw_l), c = pix - row * p.RW;
-      const int sy = ty0 - pady + row, sx = tx0 - padx + c;
-      const bool ok = q < slots && (unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win;
-      const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)gs * 16u;
-      bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);      // outside the image: hardware zero fill
+    const int rowslots = p.RW * cgp;
+    const int G = rowslots <= 32 ? 64 / rowslots : 1, GL = G * rowslots, NI = (GL + 63) >> 6;
+    if (NI == 1 || NI == 2 || NI == 4) {
+      const int sh = NI == 1 ? 0 : (NI == 2 ? 1 : 2);
+      const int LPI = (GL + NI - 1) >> sh, kp = w & (NI - 1), g0 = w >> sh, gstep = 4 >> sh;
+      const int sl = kp * LPI + lane;                                  // this lane's slot of a group
+      const int pix = (int)udiv_magic((unsigned)sl, p.div_cg_m, p.div_cg_l), gs = sl - pix * cgp;
+      const int rig = (int)udiv_magic((unsigned)pix, p.div_rw_m, p.div_rw_l), c = pix - rig * p.RW;      // row in the group, column
+      const int sx = tx0 - padx + c;
+      const bool mine = lane < LPI && sl < GL;
+      const bool colok = mine && (unsigned)sx < (unsigned)p.Win;
+      const unsigned lane_off = (unsigned)(rig * p.Win + sx) * (unsigned)pixb + (unsigned)gs * 16u;
+      for (int row0 = g0 * G; row0 < p.RH; row0 += gstep * G) {       // wave-uniform
+        const int sy0 = ty0 - pady + row0;
+        const unsigned base = (unsigned)((b * p.Hin + sy0) * p.Win) * (unsigned)pixb;
+        const bool ok = colok && (unsigned)(sy0 + rig) < (unsigned)p.Hin;
+        if (mine && row0 + rig < p.RH)                                 // (rows past the tile would land in the weights)
+          bufdma16(ok ? base + lane_off : 0x80000000u, rsrc, lds_raw + (row0 * rowslots + kp * LPI) * 16);      // outside the image: hardware zero fill
+      }
+      if (w == 0 && lane < (p.raw_bytes - slots * 16) / 16) bufdma16(0x80000000u, rsrc, lds_raw + slots * 16);     // the slack: zeros
+    } else {
+      for (int i = w; i * 64 < slots; i += 4) {
+        const int q = i * 64 + lane;
+        const int pix = (int)udiv_magic((unsigned)q, p.div_cg_m, p.div_cg_l), gs = q - pix * cgp;
+        const int row = (int)udiv_magic((unsigned)pix, p.div_rw_m, p.div_rw_l), c = pix - row * p.RW;
+        const int sy = ty0 - pady + row, sx = tx0 - padx + c;
+        const bool ok = q < slots && (unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win;
+        const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)gs * 16u;
+        bufdma16(ok ? off : 0x80000000u, rsrc, lds_raw + i * 1024);      // outside the image: hardware zero fill
+      }
     }
   }
   int off0, off1;
