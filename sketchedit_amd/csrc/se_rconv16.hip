@@ -353,15 +353,28 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
     }
   }
   __syncthreads();
+  // 128 pixels x 12 pieces of 16 bytes = 6 per thread.  A tile row is 16 x 12 = 192 pieces = three 64-lane stores: wave w
+  // stores rows w and w + 4, thirds 0, 1, 2 -- which pixel column and piece a lane stores is a per-lane constant of the
+  // third, the row arithmetic is scalar, the byte offset 32-bit (one add per store instead of ~25 VALU instructions with
+  // divisions and 64-bit address arithmetic).
+  {
+    unsigned lo[3], go[3];
+    bool cok[3];
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {                  // 128 pixels x 12 pieces of 16 bytes = 6 per thread
-    const int piece = it * 256 + tid;
-    const int pix = piece / 12, part = piece - pix * 12;
-    const int col = pix & 15;
-    const int sy = ty0 + (pix >> 4), sx = dual ? (col & 7) : tx0 + col, pxx = px + (dual ? col >> 3 : 0);
-    if (sy < p.hs && sx < p.ws)
-      *(uint4*)((char*)p.dst + ((size_t)(b * p.h + sy * p.d + py) * p.w + sx * p.d + pxx) * 192 + part * 16) =
-          *(const uint4*)(Raw + pix * OPX + part * 16);
+    for (int k = 0; k < 3; ++k) {
+      const int sl = k * 64 + lane, col = (sl * 5462) >> 16, part = sl - col * 12;      // sl / 12 (sl < 192)
+      const int sx = dual ? (col & 7) : tx0 + col, dpx = dual ? col >> 3 : 0;
+      lo[k] = (unsigned)(col * OPX + part * 16);
+      go[k] = (unsigned)(sx * p.d + dpx) * 192u + (unsigned)part * 16u;
+      cok[k] = sx < p.ws;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int k = i % 3, row = w + 4 * (i / 3);                                      // row: wave-uniform
+      const int sy = ty0 + row;
+      const unsigned gbase = (unsigned)((b * p.h + sy * p.d + py) * p.w + px) * 192u;
+      if (sy < p.hs && cok[k]) *(uint4*)((char*)p.dst + (gbase + go[k])) = *(const uint4*)(Raw + row * (16 * OPX) + lo[k]);
+    }
   }
 }
 
