@@ -718,7 +718,9 @@ __global__ __launch_bounds__(256) void att2_boxsum4_kernel(const AttParams p) {
   if (!tile_order((long)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), p.B, p.hc, p.wc, b, ry, rx)) return;
   const int r = ry * p.wc + rx;
   constexpr int ES = BF16 ? 2 : 4;
-  constexpr int G = 4;
+  // columns per lane: 4 (fp32, 16-byte loads) / 8 (bf16, 16-byte loads: with 8-byte loads the pass issues twice the
+  // vector-memory instructions per byte and runs at 3.0 instead of ~4 TB/s); G groups in flight per lane
+  constexpr int W = BF16 ? 8 : 4, G = BF16 ? 2 : 4;
   const char* Pb = (const char*)p.P + (size_t)b * p.R * p.Rp * ES;
   char* out = (char*)p.E + ((size_t)b * p.R + r) * p.Rp * ES;
   bool ok[4];
@@ -729,21 +731,23 @@ __global__ __launch_bounds__(256) void att2_boxsum4_kernel(const AttParams p) {
     ok[d] = qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;               // wave-uniform
     rowp[d] = ok[d] ? Pb + (size_t)(qy * p.wc + qx) * p.Rp * ES : Pb;   // a row that does not exist reads row 0, masked
   }
-  for (int s00 = 4 * lane; s00 < p.Rp; s00 += 256 * G) {      // Rp is a multiple of 32
-    f32x4 q[G][4];
+  for (int s00 = W * lane; s00 < p.Rp; s00 += 64 * W * G) {      // Rp is a multiple of 32 (bf16: of 64)
+    float q[G][4][W];
     float e[G][2];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int s0 = min(s00 + g * 256, p.Rp - 4);
+      const int s0 = min(s00 + g * 64 * W, p.Rp - W);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int a0 = max(s0 - (d >> 1) * p.wc, 0);
         if (BF16) {
-          const uint2 t = *(const uint2*)(rowp[d] + a0 * 2);
-          q[g][d] = (f32x4){bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y)};
+          const uint4 t = *(const uint4*)(rowp[d] + a0 * 2);
+          q[g][d][0] = bf16_lo(t.x); q[g][d][1] = bf16_hi(t.x); q[g][d][2] = bf16_lo(t.y); q[g][d][3] = bf16_hi(t.y);
+          q[g][d][4 % W] = bf16_lo(t.z); q[g][d][5 % W] = bf16_hi(t.z); q[g][d][6 % W] = bf16_lo(t.w); q[g][d][7 % W] = bf16_hi(t.w);
           if (d & 1) e[g][d >> 1] = bf16_lo(((const unsigned short*)rowp[d])[max(a0 - 1, 0)]);
         } else {
-          q[g][d] = *(const f32x4*)(rowp[d] + a0 * 4);
+          const f32x4 t = *(const f32x4*)(rowp[d] + a0 * 4);
+          q[g][d][0] = t[0]; q[g][d][1] = t[1]; q[g][d][2] = t[2]; q[g][d][3] = t[3];
           if (d & 1) e[g][d >> 1] = ((const float*)rowp[d])[max(a0 - 1, 0)];
         }
       }
@@ -751,19 +755,21 @@ __global__ __launch_bounds__(256) void att2_boxsum4_kernel(const AttParams p) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int s0 = s00 + g * 256;
+      const int s0 = s00 + g * 64 * W;
       if (s0 >= p.Rp) break;
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      float a[W];
+#pragma unroll
+      for (int u = 0; u < W; ++u) a[u] = 0.f;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int off = (d >> 1) * p.wc + (d & 1);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < W; ++u) {
           const float val = (d & 1) ? (u == 0 ? e[g][d >> 1] : q[g][d][u - 1]) : q[g][d][u];
           a[u] += (ok[d] && s0 + u >= off && s0 + u < p.R) ? val : 0.f;
         }
       }
-      if (BF16) *(uint2*)(out + s0 * 2) = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+      if (BF16) *(uint4*)(out + s0 * 2) = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4 % W], a[5 % W]), pack_bf16x2(a[6 % W], a[7 % W]));
       else *(f32x4*)(out + s0 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1186,7 +1192,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     {
       const long rows = tile_order_count(p.B, p.hc, p.wc);
       ProfScope ps_(st, PL_ATT_BOXSUM);
-      if (p.wc % 4 == 0) hipLaunchKernelGGL(att2_boxsum4_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+      if (p.wc % (BF16 ? 8 : 4) == 0) hipLaunchKernelGGL(att2_boxsum4_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
       else hipLaunchKernelGGL(att2_boxsum_kernel<BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
     }
   }
