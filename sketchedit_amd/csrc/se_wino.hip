@@ -23,8 +23,9 @@
 //   1. fp32 MFMA and VALU do not overlap on a SIMD: a wave's VALU instruction does not issue while its SIMD partner
 //      streams v_mfma_f32_16x16x4_f32 (s_setprio does not change that), and inside one wave every VALU instruction
 //      is a lost MFMA slot.  So the loop carries as few VALU instructions as possible (~25 per wave and iteration,
-//      was ~70): gather offsets and B^T factors are computed once per POSITION (source offsets live in LDS, not in
-//      registers), loads and DMA use scalar-base + 32-bit-offset addressing, the first MFMA of a position takes
+//      was ~70): gather offsets are computed once per POSITION (4 LDS reads + 4 saturating adds; source offsets live
+//      in LDS, not in registers), zero padding is the buffer range check of the gather and the B^T signs are
+//      compile-time +/- (round 3), loads and DMA use scalar-base + 32-bit-offset addressing, the first MFMA of a position takes
 //      C = 0 instead of zeroed registers, the fold generates only its 12 (of 16) non-zero terms, and there is one
 //      accumulator set -- a second one to "hide" the fold buys nothing and costs 24 registers.
 //   2. A wave that issues its 7 vector-memory instructions back to back (all 8 waves do so at the same point) stalls
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoParams p) {
 
   // fp32 MFMA and VALU instructions share the SIMD's issue time on gfx950 (a wave's VALU does not issue while its
   // SIMD partner streams fp32 MFMAs, and inside one wave every VALU instruction is a lost MFMA slot), so the loop
-  // keeps the VALU count minimal: gather offsets and transform factors are computed once per POSITION, global
-  // loads and the W DMA use scalar base + 32-bit lane offset addressing, LDS addresses are immediates.
+  // keeps the VALU count minimal: gather offsets are computed once per POSITION, the gathers and the W DMA use scalar
+  // base + 32-bit lane offset addressing, LDS addresses are immediates.
   unsigned o[4];        // byte offsets of the four source pixels of the current position (+ this lane's granule); >= 2^31: outside
-  unsigned ov[4];       // the same for the per-image vector source (NCHK == 6, src1_vec): vec_off | the validity flags
+  unsigned ov[4];       // the same for the per-image vector source (NCHK == 6, src1_vec): vec_off | the outside bit of o[i]
   const unsigned vec_off = (unsigned)bimg * 384u + lane_coff;     // per-image vector source (NCHK == 6 only)
   auto set_pos = [&](int xi, int nu) {      // xi, nu compile-time in the unrolled loop
     // B^T rows: xi=0: +d0 -d2 | 1: +d1 +d2 | 2: -d1 +d2 | 3: +d1 -d3 ; a pixel outside the image reads as zero

@@ -11,7 +11,7 @@
 //     swap in the epilogue), so a wave owns 3 row tiles x 32 tiles: 5 LDS fragment reads per 24 MFMAs (7 in
 //     se_wino.hip) and the same 24 + 96 accumulator registers.
 //   * One workgroup = 8 waves = 128 tiles; a lane stages TWO granules per iteration (same tile and slot in both
-//     k-halves), from two (offset, factor) sets: one for the even, one for the odd position of the pair.
+//     k-halves), from two offset sets: one for the even, one for the odd position of the pair.
 #include "se_device.h"
 
 #include <cstdlib>
