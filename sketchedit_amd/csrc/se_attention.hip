@@ -338,6 +338,10 @@ static hipError_t launch_attention_v1(const AttParams& p, hipStream_t st) {
 // Summation order differs from the reference's conv (fp32 rounding only): measured <= 2e-6 on `similar`.
 // =====================================================================================================================
 
+// NT_STORE: E, P and P~ are R x R matrices per image (0.5 - 1 GB per step at 512 x 512), far larger than the L2 and the
+// 256 MB Infinity Cache, written once and read a pass later: their stores are non-temporal (`global_store ... nt`).  With
+// ordinary stores the write-bound E GEMM of the bf16 mode ran at 2.5 TB/s; streaming, the same kernel takes 296 instead of
+// 426 us (512 x 512 B=16) and the pass that reads E gains 5 % (its inputs are no longer evicted by the stores).
 // BF16 (all att2 kernels): x, xn, xT, P~ and out are bf16 (8-channel granules, 64-key chunks); E, the softmax and P stay fp32.
 template <bool BF16>
 __global__ void att2_prep_kernel(const AttParams p) {
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
     const int row = rr + pr;
     const f32x4 v = *(const f32x4*)(T + row * TS + pc * 4);
     const int i = q0 + w * PT * 16 + row;
-    if (i < p.R && j < p.Rp) *(f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j) = v;
+    if (i < p.R && j < p.Rp) __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));      // streaming store (NT_STORE note at the top of this section)
   }
 }
 
@@ -641,13 +645,13 @@ __global__ __launch_bounds__(256) void att2_softmax_reg_kernel(const AttParams p
       const float a = v[k] * inv, c = v[k + 1] * inv;
       const float got = __shfl_xor((lane & 1) ? a : c, 1);
       const int s = (lane & 1) ? lane - 1 + 64 * (k + 1) : lane + 64 * k;
-      if (s < p.Rp) *(unsigned*)(P + s * 2) = (lane & 1) ? pack_bf16x2(got, c) : pack_bf16x2(a, got);
+      if (s < p.Rp) __builtin_nontemporal_store((lane & 1) ? pack_bf16x2(got, c) : pack_bf16x2(a, got), (unsigned*)(P + s * 2));
     }
   } else {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int s = lane + 64 * k;
-      if (s < p.Rp) *(float*)(P + s * 4) = v[k] * inv;
+      if (s < p.Rp) __builtin_nontemporal_store(v[k] * inv, (float*)(P + s * 4));
     }
   }
 }
@@ -769,8 +773,9 @@ __global__ __launch_bounds__(256) void att2_boxsum4_kernel(const AttParams p) {
           a[u] += (ok[d] && s0 + u >= off && s0 + u < p.R) ? val : 0.f;
         }
       }
-      if (BF16) *(uint4*)(out + s0 * 2) = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4 % W], a[5 % W]), pack_bf16x2(a[6 % W], a[7 % W]));
-      else *(f32x4*)(out + s0 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      if (BF16) __builtin_nontemporal_store((u32x4){pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4 % W], a[5 % W]), pack_bf16x2(a[6 % W], a[7 % W])}, (u32x4*)(out + s0 * 2));
+      else __builtin_nontemporal_store((f32x4){a[0], a[1], a[2], a[3]}, (f32x4*)(out + s0 * 4));
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -943,8 +948,9 @@ __global__ __launch_bounds__(512) void att2_ptilde4_kernel(const AttParams p) {
       }
     }
     if (s0 >= p.Rp || !live) return;
-    if (BF16) *(uint2*)(out + s0 * 2) = make_uint2(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1]));
-    else *(f32x4*)(out + s0 * 4) = (f32x4){acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    if (BF16) __builtin_nontemporal_store((u32x2){pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1])}, (u32x2*)(out + s0 * 2));
+    else __builtin_nontemporal_store((f32x4){acc[0][0], acc[0][1], acc[1][0], acc[1][1]}, (f32x4*)(out + s0 * 4));
   };
   // one column group per lane and step (a second group in flight was measured: no gain, and it doubles the L1 footprint)
   Grp g;
