@@ -80,6 +80,8 @@ struct Layer {
   float* d_u1 = nullptr;      // two-source 96+96 -> 192 layers: Winograd image of the FIRST source's 96 channels alone, and
   float* d_wv = nullptr;      //   the second source's direct weights [9 taps][96][192 packed rows] (vector source folded into a bias)
   float* d_wv16 = nullptr;    //   the same rounded to bf16 (kept as fp32 values) for the bf16 mode
+  float* d_u24 = nullptr;     // 96 -> 192 3x3: image of the hybrid F(2,3) x F(4,3) kernel (first 96 input channels), se_wino24.hip
+  float* d_ub24 = nullptr;    //   and the bias in its MIXED row order
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
@@ -146,6 +148,7 @@ struct se_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dry = false;
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
+  int cur_net = SE_NET_G;   // network whose plan is running (plan_netM / plan_netG; per-op entry points: G)
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
   float* vbias_ws = nullptr;       // [B][9][192] scratch for the folded vector source of the next two-source layer (plan_netG)
   const float* vec32 = nullptr;    // bf16 mode: the fp32 copy of the vector source (the conv source itself is its bf16 rounding)
@@ -191,6 +194,7 @@ int fail(se_ctx* c, const char* fmt, ...) {
 float bf16_round(float f);
 bool wino_eligible_layer(const LayerDef& d);
 int pack_wino(se_ctx* c, Layer& L);
+int pack_wino24(se_ctx* c, Layer& L);
 bool wino48_eligible_layer(const LayerDef& d);
 int pack_wino48(se_ctx* c, Layer& L);
 bool winoup_eligible_layer(const LayerDef& d);
@@ -505,6 +509,48 @@ int pack_wino(se_ctx* c, Layer& L) {
     for (auto& v : wv) v = bf16_round(v);
     HIPCHK(c, hipMemcpy(L.d_wv16, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
   }
+  return pack_wino24(c, L);
+}
+
+// Hybrid F(2,3) x F(4,3) image of the same layers (se_wino24.hip): U = Gy g Gx^T (4 x 6 positions) of the FIRST 96 input
+// channels, 72 iterations in the kernel's order -- stage (xi, h) -> chunk -> j with column position nu = {0,1,2}[j] (h = 0)
+// or {5,3,4}[j] (h = 1) --, 192 rows in the MIXED order (tile t = features 8t..8t+7, then their gates), slot swizzle as
+// everywhere.  U is formed in double and rounded once (Gx holds 1/6, 1/12, 1/24).
+int pack_wino24(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const double Gy[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
+  static const double Gx[6][3] = {{1. / 4, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                                  {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+  static const int NU[2][3] = {{0, 1, 2}, {5, 3, 4}};
+  const int NP = 192;
+  std::vector<float> img((size_t)72 * NP * 32, 0.f), bias(NP, 0.f);
+  for (int n = 0; n < NP; ++n) {
+    const int t = n / 16, r = n % 16;
+    const int oc = r < 8 ? t * 8 + r : 96 + t * 8 + (r - 8);
+    bias[n] = L.b[oc];
+    for (int ic = 0; ic < 96; ++ic) {
+      const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
+      double tt[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int kx = 0; kx < 3; ++kx) tt[i][kx] = Gy[i][0] * g[kx] + Gy[i][1] * g[3 + kx] + Gy[i][2] * g[6 + kx];
+      for (int xi = 0; xi < 4; ++xi)
+        for (int h = 0; h < 2; ++h)
+          for (int j = 0; j < 3; ++j) {
+            const int nu = NU[h][j];
+            const double u = tt[xi][0] * Gx[nu][0] + tt[xi][1] * Gx[nu][1] + tt[xi][2] * Gx[nu][2];
+            const int chunk = ic / 32, kin = ic % 32, s_ = kin / 4, e = kin % 4;
+            const int it = ((xi * 2 + h) * 3 + chunk) * 3 + j;
+            const int ps = s_ ^ ((n >> 1) & 7);
+            img[((size_t)it * NP + n) * 32 + ps * 4 + e] = (float)u;
+          }
+    }
+  }
+  if (L.d_u24) (void)hipFree(L.d_u24);
+  if (L.d_ub24) (void)hipFree(L.d_ub24);
+  HIPCHK(c, hipMalloc(&L.d_u24, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_ub24, bias.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_u24, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_ub24, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -947,7 +993,13 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
       wp.src1 = nullptr; wp.src1_vec = 0; wp.upk = L.d_u1; wp.vbias = c->vbias_ws;
       folded = true;
     }
-    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
+    // Hybrid F(2,3) x F(4,3) (se_wino24.hip) for the single-source form where the width allows 4-column tiles: 24 instead of
+    // 32 positions per 8 outputs.  SE_WINOGRAD_F43=0: F(2x2,3x3) everywhere; SE_WINOGRAD_F43=2: netG only (netM's soft mask
+    // feeds the 0.5 threshold).  Read per call: the tests compare both forms in one process.
+    const char* f43_env = getenv("SE_WINOGRAD_F43");
+    const int f43_mode = f43_env ? atoi(f43_env) : 1;
+    const bool f43 = (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && !wp.src1 && L.d_u24 && L.d_ub24 && (Win % (4 * d.rate)) == 0;
+    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = f43 ? Win / 4 : Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
     udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
@@ -955,6 +1007,13 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    if (f43) {
+      wp.upk = L.d_u24; wp.bias = L.d_ub24;
+      // 24 of 72 products per 2x4 outputs; with the vector source folded away only the first source's half of K is executed
+      set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 24.0 / 72.0 * (folded ? 0.5 : 1.0));
+      HIPCHK(c, launch_wino24(wp, c->st));
+      return 0;
+    }
     // F(2x2,3x3): 16 of 36 products; with the vector source folded away only the first source's half of K is executed
     set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 16.0 / 36.0 * (folded ? 0.5 : 1.0));
     HIPCHK(c, launch_wino(wp, c->st));
@@ -1194,6 +1253,7 @@ int small(Plan& P, const char* name, Act& in, int mode, float* out_nchw, float* 
 int plan_netM(se_ctx* c, const float* image, const float* sketch, float* mask_out, float* hard_out, float* maskim_out,
               int B, int H, int W, long packed_bs = 0) {
   Plan P(c, c->M, B);
+  c->cur_net = SE_NET_M;
   Act in = P.alloc(H, W, 4);
   if (P.rc) return P.rc;
   if (!c->dry) HIPCHK(c, c->bf16 ? launch_pack_m16(image, sketch, in.p, B, H, W, c->st) : launch_pack_m(image, sketch, in.p, B, H, W, c->st));
@@ -1217,6 +1277,7 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
               float* coarse_out, float* fine_out, const float* soft_mask, float* composed_out, int B, int H, int W,
               int flags, long packed_bs = 0) {
   Plan P(c, c->G, B);
+  c->cur_net = SE_NET_G;
   const int joint = (flags & SE_FLAG_JOINT_TRAIN_INP) ? 1 : 0;
   // joint_train_inp: the style input is packed without its (zero) guide channel and wconv1 runs as a 4-channel conv
   Act cin = P.alloc(H, W, 8);

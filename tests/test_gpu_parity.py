@@ -106,10 +106,11 @@ WINO = [(1, 16, 16, "elu"), (2, 16, 24, "elu"), (4, 16, 32, "elu"), (8, 32, 16, 
 
 
 @pytest.mark.parametrize("case", WINO, ids=["d%d-%dx%d-%s" % c for c in WINO])
-def test_op_winograd_path_vs_oracle(eng, case):
+def test_op_winograd_path_vs_oracle(eng, case, monkeypatch):
     """96 -> 192 3x3 stride 1: sizes with h % 2d == w % 2d == 0 take the Winograd F(2x2,3x3) kernel
     (se_wino.hip), the last (10x14 ... but d=1 -> eligible too) covers a ragged tile count."""
     from oracle import sketchedit_oracle as O
+    monkeypatch.setenv("SE_WINOGRAD_F43", "0")      # (the hybrid kernel has its own test below)
     d, H, W, act = case
     a = 1.5 / np.sqrt(96 * 9)
     w = synth.uniform(13, "wino.w%s" % (case,), (192, 96, 3, 3), -a, a)
@@ -118,6 +119,37 @@ def test_op_winograd_path_vs_oracle(eng, case):
     y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
     ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act)
     assert _md(y, ref) < TOL_OP
+
+
+WINO24 = [(1, 16, 16, "elu"), (1, 6, 12, "elu"), (1, 10, 20, "relu"), (2, 16, 24, "elu"), (2, 12, 8, "elu"), (4, 16, 32, "elu"),
+          (8, 32, 32, "relu"), (16, 64, 64, "elu"), (16, 32, 64, "elu"), (1, 64, 64, "elu"), (3, 12, 24, "elu")]
+
+
+@pytest.mark.parametrize("case", WINO24, ids=["d%d-%dx%d-%s" % c for c in WINO24])
+def test_op_winograd_f43_path_vs_oracle(eng, case, monkeypatch):
+    """96 -> 192 3x3 stride 1 with h % 2d == 0 and w % 4d == 0: the hybrid F(2,3) x F(4,3) kernel (se_wino24.hip, 2x4 output
+    tiles, non-dyadic transform constants) against the oracle -- dilations 1..16 (and 3: a polyphase grid that is not a
+    power of two), tile counts that are not multiples of the 32-tile workgroup (27, 75, 18), both activations -- and against
+    the F(2x2,3x3) kernel on the same input (SE_WINOGRAD_F43=0)."""
+    from oracle import sketchedit_oracle as O
+    d, H, W, act = case
+    a = 1.5 / np.sqrt(96 * 9)
+    w = synth.uniform(17, "w24.w%s" % (case,), (192, 96, 3, 3), -a, a)
+    b = synth.uniform(17, "w24.b%s" % (case,), (192,), -0.3, 0.3)
+    x = synth.uniform(17, "w24.x%s" % (case,), (3, 96, H, W), -1, 1)
+    monkeypatch.setenv("SE_WINOGRAD_F43", "1")
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
+    monkeypatch.setenv("SE_WINOGRAD_F43", "0")
+    y22 = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act)
+    assert _md(y, ref) < TOL_OP and _md(y22, ref) < TOL_OP
+    assert _md(y, y22) < 2e-5
+    # larger activations (|x| up to 8: the range the F(4,3) constants amplify): relative bound
+    x8 = x * 8.0
+    monkeypatch.setenv("SE_WINOGRAD_F43", "1")
+    y8 = eng.gated_conv2d(_cuda(x8), w, b, stride=1, rate=d, act=act)
+    ref8 = O.gated_conv(torch.from_numpy(x8), torch.from_numpy(w), torch.from_numpy(b), 1, d, act)
+    assert _md(y8, ref8) < TOL_OP * max(1.0, float(ref8.abs().max()))
 
 
 WINO48 = [(1, 16, 16, "elu"), (1, 64, 64, "elu"), (2, 16, 24, "relu"), (4, 32, 16, "elu"), (1, 10, 14, "elu"),
