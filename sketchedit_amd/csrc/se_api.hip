@@ -82,6 +82,7 @@ struct Layer {
   float* d_wv16 = nullptr;    //   the same rounded to bf16 (kept as fp32 values) for the bf16 mode
   float* d_u24 = nullptr;     // 96 -> 192 3x3: image of the hybrid F(2,3) x F(4,3) kernel (first 96 input channels), se_wino24.hip
   float* d_ub24 = nullptr;    //   and the bias in its MIXED row order
+  float* d_u24b = nullptr;    //   two-source layers: the image over both sources (6 chunks per position)
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
@@ -523,12 +524,15 @@ int pack_wino24(se_ctx* c, Layer& L) {
                                   {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
   static const int NU[2][3] = {{0, 1, 2}, {5, 3, 4}};
   const int NP = 192;
-  std::vector<float> img((size_t)72 * NP * 32, 0.f), bias(NP, 0.f);
+  // two images for the two-source layers: the first source alone (vector source folded into a bias: conv11) and both
+  // sources (allconv11: 6 chunks per position)
+  for (int nchk = 3; nchk <= d.cin / 32; nchk += 3) {
+  std::vector<float> img((size_t)24 * nchk * NP * 32, 0.f), bias(NP, 0.f);
   for (int n = 0; n < NP; ++n) {
     const int t = n / 16, r = n % 16;
     const int oc = r < 8 ? t * 8 + r : 96 + t * 8 + (r - 8);
     bias[n] = L.b[oc];
-    for (int ic = 0; ic < 96; ++ic) {
+    for (int ic = 0; ic < nchk * 32; ++ic) {
       const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
       double tt[4][3];
       for (int i = 0; i < 4; ++i)
@@ -539,18 +543,22 @@ int pack_wino24(se_ctx* c, Layer& L) {
             const int nu = NU[h][j];
             const double u = tt[xi][0] * Gx[nu][0] + tt[xi][1] * Gx[nu][1] + tt[xi][2] * Gx[nu][2];
             const int chunk = ic / 32, kin = ic % 32, s_ = kin / 4, e = kin % 4;
-            const int it = ((xi * 2 + h) * 3 + chunk) * 3 + j;
+            const int it = ((xi * 2 + h) * nchk + chunk) * 3 + j;
             const int ps = s_ ^ ((n >> 1) & 7);
             img[((size_t)it * NP + n) * 32 + ps * 4 + e] = (float)u;
           }
     }
   }
-  if (L.d_u24) (void)hipFree(L.d_u24);
-  if (L.d_ub24) (void)hipFree(L.d_ub24);
-  HIPCHK(c, hipMalloc(&L.d_u24, img.size() * 4));
-  HIPCHK(c, hipMalloc(&L.d_ub24, bias.size() * 4));
-  HIPCHK(c, hipMemcpy(L.d_u24, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(L.d_ub24, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  float*& du = nchk == 3 ? L.d_u24 : L.d_u24b;
+  if (du) (void)hipFree(du);
+  HIPCHK(c, hipMalloc(&du, img.size() * 4));
+  HIPCHK(c, hipMemcpy(du, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  if (nchk == 3) {
+    if (L.d_ub24) (void)hipFree(L.d_ub24);
+    HIPCHK(c, hipMalloc(&L.d_ub24, bias.size() * 4));
+    HIPCHK(c, hipMemcpy(L.d_ub24, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  }
+  }
   return 0;
 }
 
@@ -998,7 +1006,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     // feeds the 0.5 threshold).  Read per call: the tests compare both forms in one process.
     const char* f43_env = getenv("SE_WINOGRAD_F43");
     const int f43_mode = f43_env ? atoi(f43_env) : 1;
-    const bool f43 = (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && !wp.src1 && L.d_u24 && L.d_ub24 && (Win % (4 * d.rate)) == 0;
+    const bool f43 = (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = f43 ? Win / 4 : Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
@@ -1008,7 +1016,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
     if (f43) {
-      wp.upk = L.d_u24; wp.bias = L.d_ub24;
+      wp.upk = wp.src1 ? L.d_u24b : L.d_u24; wp.bias = L.d_ub24;
       // 24 of 72 products per 2x4 outputs; with the vector source folded away only the first source's half of K is executed
       set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 24.0 / 72.0 * (folded ? 0.5 : 1.0));
       HIPCHK(c, launch_wino24(wp, c->st));
@@ -1544,6 +1552,9 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_u1) (void)hipFree(kv.second.d_u1);
       if (kv.second.d_wv) (void)hipFree(kv.second.d_wv);
       if (kv.second.d_wv16) (void)hipFree(kv.second.d_wv16);
+      if (kv.second.d_u24) (void)hipFree(kv.second.d_u24);
+      if (kv.second.d_ub24) (void)hipFree(kv.second.d_ub24);
+      if (kv.second.d_u24b) (void)hipFree(kv.second.d_u24b);
     }
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
@@ -1918,6 +1929,9 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_u1) (void)hipFree(L.d_u1);
   if (L.d_wv) (void)hipFree(L.d_wv);
   if (L.d_wv16) (void)hipFree(L.d_wv16);
+  if (L.d_u24) (void)hipFree(L.d_u24);
+  if (L.d_ub24) (void)hipFree(L.d_ub24);
+  if (L.d_u24b) (void)hipFree(L.d_u24b);
   if (vb_test) (void)hipFree(vb_test);
   c->vbias_ws = nullptr; c->vec32 = nullptr;
   return rc;

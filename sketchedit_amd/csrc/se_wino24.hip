@@ -31,14 +31,41 @@
 //     pair as sum / difference (Ax^T columns 1,2 = (1,1,1,1), (1,-1,1,-1); columns 3,4 = (1,2,4,8), (1,-2,4,-8)):
 //     76 instead of 108 f32x4 operations per row tile.
 // Zero padding, gather offsets (saturating sums of row / column offsets kept in LDS, buffer range check), the W ring
-// (4 slots, LDS-DMA, one vmcnt(0) per iteration half an iteration after the youngest vector-memory instruction), the
-// fragment prefetch across the barrier and the spreading of vector-memory instructions over the MFMA groups are those of
-// se_wino.hip -- read that header first.  X ring: 3 sub-stage slots of 3 tiles x 4 KB.
-//   sub-stage s (iterations 3s .. 3s+2):  raw loads of sub-stage s+2 (4 + 3 + 3)  |  iteration 3s: transform of s+1
+// (LDS-DMA), the fragment prefetch across the barrier and the spreading of vector-memory instructions over the MFMA groups
+// are those of se_wino.hip -- read that header first.  W ring: 5 slots; X ring: 2 sub-stage slots of 3 tiles x 4 KB; the
+// wait schedule is described at the pipeline below.
 #include "se_device.h"
 
 #include <cstdlib>
 #include <type_traits>
+
+// Developer aid (-DSE_WINO_TRACE, tools/wino_trace.py): s_memtime stamps of block 0 / waves 0 and 4 (the two waves of SIMD 0),
+// kept in LDS; slots 0..71 = iterations, slot 72 = kernel phases (start, loop entry, loop exit, end).
+#ifdef SE_WINO_TRACE
+__device__ unsigned long long g_wino24_trace[2 * 80 * 8];
+extern "C" int se_debug_wino24_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino24_trace), sizeof(unsigned long long) * 2 * 80 * 8);
+}
+#define W24_TRACE_LDS (2 * 3 * 32 * 128 + 5 * 192 * 128 + 4 * 512 * 4 + 6 * 32 * 4)
+#define W24_STAMP_AT(slot, k)                                           \
+  do {                                                                  \
+    if (NCHK == 3 && blockIdx.x == 0 && (w & 3) == 0) {                              \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+      if (lane == 0) ((unsigned*)(smem + W24_TRACE_LDS))[((w >> 2) * 80 + (slot)) * 8 + (k)] = (unsigned)t_; \
+    }                                                                   \
+  } while (0)
+#define W24_TRACE_DUMP()                                                \
+  do {                                                                  \
+    __syncthreads();                                                    \
+    if (NCHK == 3 && blockIdx.x == 0 && (w & 3) == 0)                   \
+      for (int i_ = lane; i_ < 80 * 8; i_ += 64)                        \
+        g_wino24_trace[(w >> 2) * 80 * 8 + i_] = ((unsigned*)(smem + W24_TRACE_LDS))[(w >> 2) * 80 * 8 + i_]; \
+  } while (0)
+#else
+#define W24_TRACE_LDS 0
+#define W24_STAMP_AT(slot, k)
+#define W24_TRACE_DUMP()
+#endif
 
 namespace se {
 
@@ -52,16 +79,19 @@ DEVFN void static_for(F&& f) {
   }
 }
 
+// NCHK = 32-channel chunks per position: 3 for one 96-channel source, 6 for the two-source layer (allconv11:
+// cat([x_hallu, pm]), editline_g.py:211): chunks 3-5 are gathered from the second tensor
+template <int NCHK>
 __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
   constexpr int TILES = 32;
   constexpr int XB = TILES * 128;      // one X tile: 32 tiles x 32 k
   constexpr int XS = 3 * XB;           // one sub-stage: the X tiles of its three positions
   constexpr int WB = 192 * 128;
-  constexpr int NIT = 72, NSUB = 24;
+  constexpr int NSUB = 8 * NCHK, NIT = 3 * NSUB;      // sub-stages (xi, h, chunk); iterations
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
-  char* Wb = smem + 3 * XS;
-  int* Ysrc = (int*)(smem + 3 * XS + 4 * WB);      // [4 rows][512 threads]
+  char* Wb = smem + 2 * XS;
+  int* Ysrc = (int*)(smem + 2 * XS + 5 * WB);      // [4 rows][512 threads]
   int* Xsrc = Ysrc + 4 * 512;                      // [6 columns][32 tiles]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -70,6 +100,7 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
   const int rg = w & 3, tg = w >> 2;           // row group (3 MIXED tiles = 24 gated channels), tile group (16 tiles)
   const int tile_base = (p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TILES;
   const int tpi = p.th * p.tw;                 // tiles per image
+  W24_STAMP_AT(72, 0);
 
   // tile -> (batch, first output pixel).  (iy, ix) walks the tile grid of the d x d polyphase sub-images
   auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
@@ -118,9 +149,11 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
     }
   };
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NCHK == 6 ? p.src1 : p.src), 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
   f32x2 r[10];          // raw pieces of one task: [row][column]
   auto load_x1 = [&](int chunk, int i) {       // piece i = row * 5 + column: one vector-memory instruction
-    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs0, (int)o[i / 5][i % 5], chunk * 128, 0);
+    const u32x2 t = chunk >= 3 ? __builtin_amdgcn_raw_buffer_load_b64(rs1, (int)o[i / 5][i % 5], (chunk - 3) * 128, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b64(rs0, (int)o[i / 5][i % 5], chunk * 128, 0);
     r[i] = __builtin_bit_cast(f32x2, t);
   };
   // opaque constants: the transform stays packed fmas (a plain a - b on a vector becomes scalar v_sub per element)
@@ -223,10 +256,23 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: W slots 0, 1, 2; X sub-stage 0 transformed; raw pieces of sub-stage 1 in flight in r
+  // ---- pipeline.  One workgroup barrier per iteration; W tiles in a 5-slot ring, X sub-stages in a 2-slot ring.  The
+  // vector-memory instructions of a sub-stage s (iterations 3s .. 3s+2; F / S = first / second half of an iteration) are
+  // placed so that there is ONE full wait per sub-stage and it never meets an instruction younger than ~one iteration:
+  //   3s   : mid: vmcnt(0), transform of task s+1 -> X slot (s+1)%2 | S: raw pieces 0-3 of task s+2, W(3s+4)
+  //   3s+1 : F: raw pieces 4-6                                      | S: raw pieces 7-9, W(3s+5)
+  //   3s+2 : F: W(3s+6) | mid: vmcnt(K): W(3s+4) has landed (K = the vector-memory instructions issued after it)
+  //   W(it+4) -> slot (it+4)%5 = the slot of it-1, free since the barrier of it-1; complete at a mid-iteration wait of
+  //   it+2 at the latest, published by that iteration's barrier, first read (k-half 0 fragments) in the second half of it+3
+  //   X(s+1): slot last read in sub-stage s-1; written at mid 3s, published by the barrier of 3s, first read in 3s+2
+  // (the first version waited vmcnt(0) in EVERY iteration, half an iteration after the youngest instruction: the cycle
+  // trace showed both waves of a SIMD idle ~150 of 2200 cycles per iteration in that wait)
+  // The raw loads are ordinary loads that hipcc tracks itself (se_wino.hip); the W DMA is hidden from it, so its own wait
+  // in front of the transform is a vmcnt(0) as well.
+  // ---- prologue: W slots 0..3; X sub-stage 0 transformed; raw pieces of sub-stage 1 in flight in r
   set_offs(0);
 #pragma unroll
-  for (int i0 = 0; i0 < 3; ++i0) {     // the W DMA first: its latency overlaps the raw round trip
+  for (int i0 = 0; i0 < 4; ++i0) {     // the W DMA first: its latency overlaps the raw round trip
     dma_w(i0, i0, 0);
     dma_w(i0, i0, 1);
     dma_w(i0, i0, 2);
@@ -247,20 +293,22 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) wa[t] = *(const f32x4*)(Ww + t * 2048 + off0);
 
+  W24_STAMP_AT(72, 1);
   // stages x (chunk, j), fully unrolled through a compile-time index (72 bodies are beyond what `#pragma unroll` accepts):
   // everything below is compile-time
   static_for<0, NIT>([&](auto it_c) __attribute__((always_inline)) {
     constexpr int it = decltype(it_c)::value;
-    constexpr int st = it / 9, q = it % 9, s = it / 3, j = q % 3, chunk = q / 3;
-    const int w0 = it % 4, w1 = (it + 1) % 4, w3 = (it + 3) % 4;                 // W ring
-    const bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
-    const int ls = s + 2;              // sub-stage whose raw pieces are fetched during this one
-    const bool ld = ls < NSUB;
+    constexpr int st = it / (3 * NCHK), q = it % (3 * NCHK), s = it / 3, j = q % 3, chunk = q / 3;
+    constexpr int w0 = it % 5, w1 = (it + 1) % 5, w4 = (it + 4) % 5;             // W ring
+    constexpr bool more1 = it + 1 < NIT, more4 = it + 4 < NIT;
+    constexpr int ls = s + 2;          // sub-stage whose raw pieces are fetched during this one
+    constexpr bool ld = ls < NSUB;
     f32x4 wb[3], xb;
-    xb = *(const f32x4*)(Xw + (s % 3) * XS + j * XB + off1);            // k-half 1 fragments of this iteration
+    xb = *(const f32x4*)(Xw + (s % 2) * XS + j * XB + off1);            // k-half 1 fragments of this iteration
 #pragma unroll
     for (int t = 0; t < 3; ++t) wb[t] = *(const f32x4*)(Ww + w0 * WB + t * 2048 + off1);
     __builtin_amdgcn_sched_barrier(0);
+    W24_STAMP_AT(it, 0);
     // one group = 3 MFMAs: k-step e of the three row tiles; `first`: C = 0 (first k-step of a position)
     auto group = [&](const f32x4 (&wf)[3], const f32x4& xf, int e, bool first) {
 #pragma unroll
@@ -270,40 +318,62 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    if (q == 7) { fold_single(st); __builtin_amdgcn_sched_barrier(0); }              // am[0] was completed in q = 6
+    if (q == 3 * NCHK - 2) { fold_single(st); __builtin_amdgcn_sched_barrier(0); }   // am[0] was completed in the iteration before
     if (q == 0 && st > 0) { fold_pair(st - 1); __builtin_amdgcn_sched_barrier(0); }  // am[1], am[2] of the previous stage
     group(wa, xa, 0, chunk == 0);
-    group(wa, xa, 1, false);
-    group(wa, xa, 2, false);
-    group(wa, xa, 3, false);
-    if (more2) dma_wait_all();           // raw pieces and W DMA issued in the second half of the previous iteration
-    if (j == 0 && s + 1 < NSUB) transform((s + 1) / 3, (s + 1) % 3);
-    if (j == 0 && ld && ls % 3 == 0) set_offs(ls / 3);
+    if (j == 1 && ld) load_x1(ls % NCHK, 4);
+    if (j == 2 && more4) dma_w(it + 4, w4, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // vector-memory instructions spread over the MFMA groups of the second half (se_wino.hip, point 2)
-    const int lb = j == 0 ? 0 : (j == 1 ? 4 : 7);        // first raw piece of this iteration: 4 + 3 + 3
+    group(wa, xa, 1, false);
+    if (j == 1 && ld) load_x1(ls % NCHK, 5);
+    if (j == 2 && more4) dma_w(it + 4, w4, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    group(wa, xa, 2, false);
+    if (j == 1 && ld) load_x1(ls % NCHK, 6);
+    if (j == 2 && more4) dma_w(it + 4, w4, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    group(wa, xa, 3, false);
+    W24_STAMP_AT(it, 1);
+    if (j == 0) {
+      dma_wait_all();                    // everything issued so far: the youngest is the W DMA of the first half of it-1
+      if (s + 1 < NSUB) transform((s + 1) / NCHK, (s + 1) % 2);
+      if (ld && ls % NCHK == 0) set_offs(ls / NCHK);
+    }
+    if (j == 2 && it + 2 < NIT) {        // W(it+2) was issued in the second half of it-2, in front of K younger instructions
+      constexpr int K = 7 * (ld ? 1 : 0) + 3 * ((it - 1 + 4 < NIT ? 1 : 0) + (more4 ? 1 : 0));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    W24_STAMP_AT(it, 2);
+    // vector-memory instructions spread over the MFMA groups (se_wino.hip, point 2)
     group(wb, xb, 0, false);
-    if (more3) dma_w(it + 3, w3, 0);
-    if (ld) load_x1(ls % 3, lb);
+    if (j == 0 && ld) load_x1(ls % NCHK, 0);
+    if (j == 1 && ld) load_x1(ls % NCHK, 7);
+    if (j != 2 && more4) dma_w(it + 4, w4, 0);
     if (more1) {                                          // k-half 0 fragments of it+1 (published slots)
-      xa = *(const f32x4*)(Xw + (((it + 1) / 3) % 3) * XS + ((it + 1) % 3) * XB + off0);
+      xa = *(const f32x4*)(Xw + (((it + 1) / 3) % 2) * XS + ((it + 1) % 3) * XB + off0);
 #pragma unroll
       for (int t = 0; t < 3; ++t) wa[t] = *(const f32x4*)(Ww + w1 * WB + t * 2048 + off0);
     }
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 1, false);
-    if (more3) dma_w(it + 3, w3, 1);
-    if (ld) load_x1(ls % 3, lb + 1);
+    if (j == 0 && ld) load_x1(ls % NCHK, 1);
+    if (j == 1 && ld) load_x1(ls % NCHK, 8);
+    if (j != 2 && more4) dma_w(it + 4, w4, 1);
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 2, false);
-    if (more3) dma_w(it + 3, w3, 2);
-    if (ld) load_x1(ls % 3, lb + 2);
+    if (j == 0 && ld) load_x1(ls % NCHK, 2);
+    if (j == 1 && ld) load_x1(ls % NCHK, 9);
+    if (j != 2 && more4) dma_w(it + 4, w4, 2);
     __builtin_amdgcn_sched_barrier(0);
     group(wb, xb, 3, false);
-    if (ld && j == 0) load_x1(ls % 3, lb + 3);
+    if (j == 0 && ld) load_x1(ls % NCHK, 3);
     __builtin_amdgcn_sched_barrier(0);
+    W24_STAMP_AT(it, 3);
     end_barrier();
+    W24_STAMP_AT(it, 4);
   });
+  W24_STAMP_AT(72, 2);
   fold_pair(7);
 
   // ---- epilogue (se_wino48.hip).  Lane (q = lane>>4, col = lane&15) holds rows 4q..4q+3 of every accumulator tile:
@@ -341,19 +411,26 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
           *(float2*)((char*)p.dst + (dst0 + (unsigned)a * dinc_y + (unsigned)bb * dinc_x + (unsigned)c0 * 4u)) = ov;      // 32-bit offset: the launch guards the bytes
       }
   }
+  W24_STAMP_AT(72, 3);
+  W24_TRACE_DUMP();
 }
 
-hipError_t launch_wino24(const WinoParams& p, hipStream_t st) {
-  constexpr int LDS = 3 * 3 * 32 * 128 + 4 * 192 * 128 + 4 * 512 * 4 + 6 * 32 * 4;     // X ring 36 KB + W ring 96 KB + source offsets 8.75 KB
+template <int NCHK>
+static hipError_t launch_wino24_t(const WinoParams& p, hipStream_t st) {
+  constexpr int LDS = 2 * 3 * 32 * 128 + 5 * 192 * 128 + 4 * 512 * 4 + 6 * 32 * 4 + (W24_TRACE_LDS ? 2 * 80 * 8 * 4 : 0);     // X ring 24 KB + W ring 120 KB + source offsets 8.75 KB
   {
-    hipError_t e = ensure_max_lds((const void*)wino24_kernel, LDS);
+    hipError_t e = ensure_max_lds((const void*)wino24_kernel<NCHK>, LDS);
     if (e != hipSuccess) return e;
   }
   const int grid = (p.total_tiles + 31) / 32;
   set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_N192);
-  hipLaunchKernelGGL(wino24_kernel, dim3(grid), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL(wino24_kernel<NCHK>, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
+}
+
+hipError_t launch_wino24(const WinoParams& p, hipStream_t st) {
+  return p.src1 ? launch_wino24_t<6>(p, st) : launch_wino24_t<3>(p, st);
 }
 
 }  // namespace se

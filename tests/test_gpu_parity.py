@@ -220,6 +220,27 @@ def test_op_two_source_conv_vs_oracle(eng, case, ll):
     assert _md(y, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("size", [(16, 16), (12, 20), (6, 8), (64, 64)], ids=lambda s: "%dx%d" % s)
+def test_op_two_source_winograd_forms_vs_oracle(eng, size, monkeypatch):
+    """allconv11 (editline_g.py:211, cat([x_hallu, pm])): the two-tensor layer in the hybrid F(2,3) x F(4,3) form
+    (wino24_kernel<6>: chunks 3-5 of every position gathered from the second tensor) and in the F(2x2,3x3) form
+    (wino_kernel<6>, SE_WINOGRAD_F43=0), both against the oracle on the materialised concat."""
+    from oracle import sketchedit_oracle as O
+    H, W = size
+    a = 1.5 / np.sqrt(192 * 9)
+    w = synth.uniform(29, "two24.w", (192, 192, 3, 3), -a, a)
+    b = synth.uniform(29, "two24.b", (192,), -0.3, 0.3)
+    x = synth.uniform(29, "two24.x%s" % (size,), (3, 96, H, W), -1, 1)
+    x1 = synth.uniform(29, "two24.y%s" % (size,), (3, 96, H, W), -1, 1)
+    ref = O.gated_conv(torch.from_numpy(np.concatenate([x, x1], 1)), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu")
+    monkeypatch.setenv("SE_WINOGRAD_F43", "1")
+    y24 = eng.gated_conv2d(_cuda(x), w, b, x1=_cuda(x1))
+    monkeypatch.setenv("SE_WINOGRAD_F43", "0")
+    y22 = eng.gated_conv2d(_cuda(x), w, b, x1=_cuda(x1))
+    assert _md(y24, ref) < TOL_OP and _md(y22, ref) < TOL_OP
+    assert _md(y24, y22) < 2e-5
+
+
 @pytest.mark.parametrize("shape", NET_SHAPES, ids=["%d-%d-s%d-d%d-u%d-k%d" % s for s in NET_SHAPES])
 def test_op_low_latency_shapes_vs_oracle(eng, shape):
     """Every layer shape of the network in its small-grid launch shape (SE_FLAG_LOW_LATENCY: 64-pixel tiles, the wide

@@ -88,5 +88,33 @@ def run48():
         print("wave %d: prologue %d  loop %d  epilogue %d cycles" % (wv * 4, e[1] - e[0], e[2] - e[1], e[3] - e[2]))
 
 
+def run24():
+    """hybrid F(2,3) x F(4,3) kernel (se_wino24.hip): 72 iterations of 24 MFMAs per wave; slot 72 = kernel phases"""
+    os.environ["SKETCHEDIT_HIP_LIB"] = SO
+    os.environ["SE_WINOGRAD_F43"] = "1"
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    from sketchedit_amd import synth
+    from sketchedit_amd._lib import Engine
+    a = 1.5 / np.sqrt(96 * 9)
+    w = synth.uniform(1, "t.w", (192, 96, 3, 3), -a, a)
+    b = synth.uniform(1, "t.b", (192,), -0.1, 0.1)
+    x = torch.from_numpy(synth.uniform(1, "t.x", (32, 96, 64, 64), -1, 1)).cuda()
+    lib = ctypes.CDLL(SO)
+    buf = (ctypes.c_ulonglong * (2 * 80 * 8))()
+    eng = Engine(0)
+    for _ in range(3):
+        eng.gated_conv2d(x, w, b)
+    torch.cuda.synchronize()
+    assert lib.se_debug_wino24_trace(buf) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 80, 8).astype(np.int64)
+    print("== wino24_kernel (se_wino24.hip)")
+    table(t, ["fold+12mfma", "wait/xform", "12mfma+ld", "barrier"], 5, nit=72)
+    for wv in range(2):
+        e = t[wv, 72]
+        print("wave %d: prologue %d  loop %d  epilogue %d cycles (s_memtime ticks: 100 MHz)" % (wv * 4, e[1] - e[0], e[2] - e[1], e[3] - e[2]))
+
+
 if __name__ == "__main__":
-    {"build": build, "run": run, "run48": run48}[sys.argv[1]]()
+    {"build": build, "run": run, "run48": run48, "run24": run24}[sys.argv[1]]()
