@@ -7,7 +7,8 @@ models/create_mask.py:1 imports cv2 (train-only, absent here).  Procedural weigh
 from sketchedit_amd.synth are injected with load_state_dict.  Only the produced
 vectors (inputs are regenerated from the seed) are committed -- no reference source.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py              # everything
+    python tests/golden/make_golden.py --round4     # only the fixtures added in round 4 (512x512, samples, weight sets)
 """
 import os
 import sys
@@ -30,7 +31,7 @@ from sketchedit_amd import synth  # noqa: E402
 torch.set_num_threads(8)
 
 
-def build_reference(gain, seed=0, **over):
+def build_reference(gain, seed=0, dist="uniform", **over):
     import models  # the reference's models/__init__.py
     o = dict(gpu_ids=[], isTrain=False, model="editline2", netG="deepfillc2",
              init_type="xavier", init_variance=0.02, use_cam=True, pool_type="max",
@@ -39,8 +40,8 @@ def build_reference(gain, seed=0, **over):
              checkpoints_dir="./checkpoints", name="celeb")
     o.update(over)
     m = models.create_model(Namespace(**o)).eval()
-    sdG = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", seed, gain).items()}
-    sdM = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", seed, gain).items()}
+    sdG = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", seed, gain, dist).items()}
+    sdM = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", seed, gain, dist).items()}
     m.netG.load_state_dict(sdG)      # strict: key/shape contract check
     m.netM.load_state_dict(sdM)
     return m
@@ -209,7 +210,119 @@ def face_case(m):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4 (VERDICT r3 items 1, 4 of "What's missing"): reference-generated vectors at BASELINE config-3 size, on every
+# bundled sample, and for more than one weight set.  Large tensors are carried as four 64x64 crops (two of them touching
+# an image border), per-row and per-column sums of every channel (a localised defect ANYWHERE moves one of them) and the
+# five global statistics of summary().
+# ------------------------------------------------------------------------------------------------------------------
+def crop_boxes(H, W):
+    """(top, left) of the four 64x64 crops: top-left corner, bottom-right corner, centre, and an off-centre interior one."""
+    return [(0, 0), (H - 64, W - 64), ((H - 64) // 2, (W - 64) // 2), (min((H // 4) // 8 * 8, H - 64), min((5 * W // 8) // 8 * 8, W - 64))]
+
+
+def digest(name, a, out, crops=True):
+    """a: (B,C,H,W) float tensor of the reference -> crops, row / column sums, global statistics under keys name_*"""
+    a = a.numpy() if hasattr(a, "numpy") else a
+    H, W = a.shape[2:]
+    out[name + "_sum"] = summary(a)
+    out[name + "_rows"] = a.astype(np.float64).sum(3).astype(np.float32)
+    out[name + "_cols"] = a.astype(np.float64).sum(2).astype(np.float32)
+    if crops:
+        out[name + "_crops"] = np.stack([a[:, :, t:t + 64, l:l + 64] for t, l in crop_boxes(H, W)], 0).astype(np.float32)
+
+
+def similar_digest(sim):
+    """similar (B, L, hs, ws) = softmax over the L keys for every query position: per query the largest probability, its
+    key index, and a position-weighted checksum sum_k p_k * ((k * 37) % 101) / 101 (a permutation or a shift of keys moves it)"""
+    B, L = sim.shape[:2]
+    p = sim.reshape(B, L, -1).numpy().astype(np.float64)          # [B][key][query]
+    wk = ((np.arange(L) * 37) % 101 / 101.0)[None, :, None]
+    return dict(similar_max=p.max(1).astype(np.float32), similar_argmax=p.argmax(1).astype(np.int32),
+                similar_chk=(p * wk).sum(1).astype(np.float32), similar_sum=summary(p))
+
+
+def run_digest(m, img, sk, want_similar=False):
+    """one inference of the reference on (img, sk) tensors -> digest dictionary"""
+    out = {}
+    taps = {}
+    with torch.no_grad():
+        composed, soft = m({"image": img, "mask": sk, "gt": img, "edgegt": sk}, mode="inference")
+        hard = (soft > 0.5).float()
+        hk = m.netG.cam_1.register_forward_hook(lambda mod, i, o: taps.__setitem__("similar", o))
+        coarse, fine = m.netG(img, img, hard, hard, sk)
+        hk.remove()
+    for k, v in (("composed", composed), ("mask", soft), ("coarse", coarse), ("fine", fine)):
+        digest(k, v, out, crops=k in ("composed", "mask"))      # the two stage outputs: row / column sums and statistics only
+    out["hard_mask_bits"] = np.packbits(hard.numpy().astype(np.uint8))
+    out["hole_fraction"] = np.array([float(hard.mean())], np.float64)
+    out["composed_u8_crops"] = np.stack([((composed + 1) / 2 * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)[t:t + 64, l:l + 64]
+                                         for t, l in crop_boxes(*composed.shape[2:])], 0)               # test.py:25-35
+    if want_similar:
+        out.update(similar_digest(taps["similar"]))
+    return out, dict(composed=composed, mask=soft, hard_mask=hard, coarse=coarse, fine=fine)
+
+
+SAMPLES = [("face_release", "822_images_celeb_03375"), ("face_release", "873_images_celeb_22553"),
+           ("face_release", "902_images_celeb_16692"), ("general_release", "11"), ("general_release", "556"),
+           ("general_release", "830"), ("general_release", "854")]
+
+
+def sample_case(m, rel, name):
+    """one bundled sample as /root/reference/data/testimage_dataset.py:89-111 loads it (the first face is c1_face.npz)"""
+    from PIL import Image
+    image = Image.open("/root/reference/datasets/%s/images/%s.png" % (rel, name)).convert("RGB")
+    w, h = image.size
+    sketch = Image.open("/root/reference/datasets/%s/edges/%s.png" % (rel, name)).convert("L").resize((w, h))
+    iu8, su8 = np.asarray(image, np.uint8), np.asarray(sketch, np.uint8)
+    img = torch.from_numpy(((iu8.astype(np.float32).transpose(2, 0, 1) / 255.0) - 0.5) / 0.5)[None]
+    sk = torch.from_numpy((su8.astype(np.float32)[None, None] / 255.0 > 0).astype(np.float32))
+    out, _ = run_digest(m, img, sk)
+    # the two input images as the dataset holds them (PNG bytes: data, and half the size of the decoded array in an npz)
+    out["image_png"] = np.frombuffer(open("/root/reference/datasets/%s/images/%s.png" % (rel, name), "rb").read(), np.uint8)
+    out["sketch_png"] = np.frombuffer(open("/root/reference/datasets/%s/edges/%s.png" % (rel, name), "rb").read(), np.uint8)
+    print("%s/%s: %dx%d sketch density %.4f hole fraction %.3f" % (rel, name, h, w, float(sk.mean()), float(out["hole_fraction"][0])))
+    return out
+
+
+def round4():
+    gain = synth.DEFAULT_GAIN
+    m = build_reference(gain)
+    # ---- BASELINE config 3 size: 512x512, B=1, seed 1234, attention with L = 3969 keys ---------------------------
+    img, sk = synth.make_inputs(1, 512, 512, seed=1234)
+    out, _ = run_digest(m, torch.from_numpy(img), torch.from_numpy(sk), want_similar=True)
+    out["meta"] = np.array([gain, 0, 1234, 1, 512, 512], np.float64)
+    print("512x512 hole fraction %.3f" % float(out["hole_fraction"][0]))
+    np.savez_compressed(os.path.join(HERE, "e2e_512.npz"), **out)
+    # ---- the 256x256 case of e2e_256.npz again, with four crops and the row / column sums ------------------------
+    img, sk = synth.make_inputs(1, 256, 256, seed=1234)
+    out, _ = run_digest(m, torch.from_numpy(img), torch.from_numpy(sk), want_similar=True)
+    out["meta"] = np.array([gain, 0, 1234, 1, 256, 256], np.float64)
+    np.savez_compressed(os.path.join(HERE, "e2e_256_crops.npz"), **out)
+    # ---- the other seven bundled samples (three faces, three 512x512 scenes, the 408x512 scene) -------------------
+    for rel, name in SAMPLES:
+        np.savez_compressed(os.path.join(HERE, "sample_%s.npz" % name.split("_")[0]), **sample_case(m, rel, name))
+    # ---- further weight sets: 64x64 B=2 in full, 256x256 B=1 as a digest --------------------------------------------
+    for ws in ("w1", "w2"):
+        seed, g, dist = synth.WEIGHT_SETS[ws]
+        mw = build_reference(g, seed, dist)
+        img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+        o64, full = run_digest(mw, torch.from_numpy(img), torch.from_numpy(sk))
+        keep = {k: v.numpy().astype(np.float32) for k, v in full.items()}
+        img, sk = synth.make_inputs(1, 256, 256, seed=1234)
+        o256, _ = run_digest(mw, torch.from_numpy(img), torch.from_numpy(sk), want_similar=True)
+        keep.update({"d256." + k: v for k, v in o256.items()})
+        print("%s: hole fraction %.3f (64x64), %.3f (256x256)" % (ws, float(o64["hole_fraction"][0]), float(o256["hole_fraction"][0])))
+        assert 0.1 < float(o64["hole_fraction"][0]) < 0.95 and 0.1 < float(o256["hole_fraction"][0]) < 0.95
+        np.savez_compressed(os.path.join(HERE, "weights_%s.npz" % ws), **keep)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
+
+
 def main():
+    if "--round4" in sys.argv:
+        return round4()
     gain = synth.DEFAULT_GAIN
     m = build_reference(gain)
     if "--only-face" in sys.argv:
@@ -268,9 +381,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "c1_face.npz"), meta=np.array([gain, 0], np.float64), **face_case(m))
     # ---- per-op known answers ------------------------------------------------------
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **op_cases())
-    for f in sorted(os.listdir(HERE)):
-        if f.endswith(".npz"):
-            print("%-20s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
+    round4()
 
 
 if __name__ == "__main__":

@@ -117,6 +117,74 @@ def test_e2e_256(golden_dir):
         np.testing.assert_allclose(_summary(out[k]), g[k + "_sum"], rtol=2e-5, atol=2e-4)
 
 
+def _oracle_forward(WM, WG, img, sk):
+    """netM -> threshold -> netG -> composite with the attention's `similar` tapped (O.inference does not return it)"""
+    img, sk = torch.from_numpy(np.asarray(img)), torch.from_numpy(np.asarray(sk))
+    taps = {}
+    with torch.no_grad():
+        mask, _ = O.netM_forward(WM, img, sk, want_image=False)
+        hard = (mask > 0.5).float()
+        coarse, fine = O.netG_forward(WG, img, img, hard, hard, sk, taps=taps)
+    return dict(mask=mask, hard=hard, coarse=coarse, fine=fine, composed=fine * mask + img * (1 - mask), similar=taps["similar"])
+
+
+@pytest.mark.parametrize("name", ["e2e_512.npz", "e2e_256_crops.npz"])
+def test_e2e_digest_512_and_256(golden_dir, name):
+    """BASELINE config-3 size (512x512: attention over L = 3969 keys, /root/reference/models/networks/splitcam.py:57-108) and
+    the 256x256 case again, against the reference's four crops (two on an image border), row / column sums of all four
+    outputs, hard-mask bits, and the per-query digests of `similar`."""
+    from digest_util import check_digest, check_similar
+    g = _load(golden_dir, name)
+    gain, wseed, iseed, B, H, W = g["meta"]
+    WM, WG = _weights(float(gain))
+    img, sk = synth.make_inputs(int(B), int(H), int(W), seed=int(iseed))
+    r = _oracle_forward(WM, WG, img, sk)
+    assert check_digest(r, g, tol=5e-6, sum_atol=4e-6 * max(H, W)) < 5e-6
+    assert tuple(r["similar"].shape[1:]) == ((H // 8 - 1) * (W // 8 - 1), H // 8 - 1, W // 8 - 1)
+    check_similar(r["similar"], g, tol=2e-5)
+
+
+SAMPLE_IDS = ["822", "873", "902", "11", "556", "830", "854"]
+
+
+@pytest.mark.parametrize("sid", SAMPLE_IDS)
+def test_bundled_samples(golden_dir, sid):
+    """The other seven bundled samples (/root/reference/datasets/face_release/list.txt: three more 256x256 faces;
+    general_release/list.txt, test_places.sh:1-17: three 512x512 scenes and the 408-wide one), inputs decoded from the PNG
+    bytes the fixture carries, against the reference's outputs on them."""
+    from digest_util import check_digest, sample_inputs
+    g = _load(golden_dir, "sample_%s.npz" % sid)
+    WM, WG = _weights(synth.DEFAULT_GAIN)
+    img, sk = sample_inputs(g)
+    assert 0.0005 < float(sk.mean()) < 0.01
+    r = _oracle_forward(WM, WG, img, sk)
+    assert abs(float(r["hard"].mean()) - float(g["hole_fraction"][0])) < 1e-6
+    check_digest(r, g, tol=5e-6, sum_atol=4e-6 * max(img.shape[2:]))      # (a row sum adds up to 512 per-pixel differences)
+    got = ((r["composed"] + 1) / 2 * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)        # test.py:25-35
+    from digest_util import crop_boxes
+    for i, (t, l) in enumerate(crop_boxes(*got.shape[:2])):
+        d = np.abs(got[t:t + 64, l:l + 64].astype(int) - g["composed_u8_crops"][i].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3
+
+
+@pytest.mark.parametrize("ws", ["w1", "w2"])
+def test_further_weight_sets(golden_dir, ws):
+    """The same forward under two more procedural weight sets (synth.WEIGHT_SETS: another seed at a larger gain, and a
+    heavier-tailed Laplace draw): 64x64 B=2 in full, 256x256 B=1 as a digest."""
+    from digest_util import check_digest, check_similar
+    g = _load(golden_dir, "weights_%s.npz" % ws)
+    WM, WG = synth.make_weight_set("M", ws), synth.make_weight_set("G", ws)
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    r = _oracle_forward(WM, WG, img, sk)
+    assert np.array_equal(r["hard"].numpy(), g["hard_mask"])
+    for k in ("composed", "mask", "coarse", "fine"):
+        assert _maxdiff(r[k], g[k]) < 5e-6, k
+    img, sk = synth.make_inputs(1, 256, 256, seed=1234)
+    r = _oracle_forward(WM, WG, img, sk)
+    check_digest(r, g, tol=1e-5, sum_atol=4e-6 * 256, prefix="d256.")
+    check_similar(r["similar"], g, tol=2e-5, prefix="d256.")
+
+
 def _face_inputs(g):
     """The tensors /root/reference/data/testimage_dataset.py:89-111 builds from the two bundled images."""
     img = torch.from_numpy(((g["image_u8"].astype(np.float32).transpose(2, 0, 1) / 255.0) - 0.5) / 0.5)[None]

@@ -21,15 +21,19 @@ FLAGS = 1 | 2 | 16
 def run(n, seed, verbose=True):
     rng = np.random.RandomState(seed)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    WM, WG = synth.make_state_dict("M", 0), synth.make_state_dict("G", 0)
+    # every case draws one of the procedural weight sets (synth.WEIGHT_SETS: two seeds / gains of the uniform draw and a
+    # heavier-tailed Laplace draw): one engine per (weight set, precision)
+    names = sorted(synth.WEIGHT_SETS)
+    wts = {ws: (synth.make_weight_set("M", ws), synth.make_weight_set("G", ws)) for ws in names}
     engs = {}
-    for prec in ("f32", "bf16"):
-        e = Engine(0)
-        e.load_state_dict("M", WM)
-        e.load_state_dict("G", WG)
-        if prec == "bf16":
-            e.set_precision("bf16")
-        engs[prec] = e
+    for ws in names:
+        for prec in ("f32", "bf16"):
+            e = Engine(0)
+            e.load_state_dict("M", wts[ws][0])
+            e.load_state_dict("G", wts[ws][1])
+            if prec == "bf16":
+                e.set_precision("bf16")
+            engs[ws, prec] = e
     worst = {"f32": 0.0, "bf16": 0.0}
     bad = 0
     t0 = time.time()
@@ -38,6 +42,8 @@ def run(n, seed, verbose=True):
         H, W = 8 * int(rng.randint(2, 20)), 8 * int(rng.randint(2, 20))
         prec = "bf16" if k % 3 == 2 else "f32"
         ll = bool(rng.randint(0, 2))
+        ws = names[int(rng.randint(0, len(names)))]
+        WM, WG = wts[ws]
         img, sk = synth.make_inputs(B, H, W, seed=100 + k)
         # one case in four: a random combination of the option flags (editline_g.py:15-23) instead of test_celeb.sh's
         fl = dict(use_cam=True, pool_type="max", no_mask_cc=False, no_mask_coarse=False, joint_train_inp=True)
@@ -47,7 +53,7 @@ def run(n, seed, verbose=True):
         bits = (1 if fl["use_cam"] else 0) | (2 if fl["pool_type"] == "max" else 0) | (4 if fl["no_mask_cc"] else 0) | \
             (8 if fl["no_mask_coarse"] else 0) | (16 if fl["joint_train_inp"] else 0)
         ref = O.inference(WM, WG, img, sk, act_dtype=torch.bfloat16 if prec == "bf16" else None, **fl)
-        e = engs[prec]
+        e = engs[ws, prec]
         ci, cs = torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda()
         r = e.inference(ci, cs, bits, visualize=True, low_latency=ll)
         hard = ref["hard_mask"].cuda()
@@ -55,12 +61,21 @@ def run(n, seed, verbose=True):
         dm = float((r["mask"].cpu() - ref["mask"]).abs().max())
         dc = float((coarse.cpu() - ref["coarse"]).abs().max())
         df = float((fine.cpu() - ref["fine"]).abs().max())
-        tol = 1e-3 if prec == "f32" else 3e-2
+        tol = 1e-3
+        if prec == "bf16":
+            # the comparator is self-defined (the reference has no reduced precision): two valid placements of the same bf16
+            # roundings differ by 3e-2 at the default gain, and by more under the larger-gain weight set -- there the bound is
+            # the error triangle of tests/test_gpu_bf16.py: no further from the bf16 oracle than 1.25 x the bf16 oracle's own
+            # distance from the fp32 oracle
+            r32 = O.inference(WM, WG, img, sk, **fl)
+            _, f32g = O.netG_forward(WG, *[torch.from_numpy(a) for a in (img, img)], ref["hard_mask"], ref["hard_mask"], torch.from_numpy(sk), **fl)
+            tri = max(float((ref["mask"] - r32["mask"]).abs().max()), float((ref["fine"] - f32g).abs().max()))
+            tol = max(3e-2, 1.25 * tri)
         ok = dm < tol and dc < tol and df < tol and np.isfinite(dm + dc + df)
         worst[prec] = max(worst[prec], dm, dc, df)
         bad += 0 if ok else 1
         if verbose or not ok:
-            print("%2d %-4s B=%d %3dx%-3d ll=%d fl=%-2d mask %.2e coarse %.2e fine %.2e %s" % (k, prec, B, H, W, ll, bits, dm, dc, df, "ok" if ok else "FAIL"), flush=True)
+            print("%2d %-4s %s B=%d %3dx%-3d ll=%d fl=%-2d mask %.2e coarse %.2e fine %.2e %s" % (k, prec, ws, B, H, W, ll, bits, dm, dc, df, "ok" if ok else "FAIL"), flush=True)
     for e in engs.values():
         e.close()
     print("cases %d  failures %d  worst f32 %.2e  worst bf16 %.2e  (%.0f s)" % (n, bad, worst["f32"], worst["bf16"], time.time() - t0))
