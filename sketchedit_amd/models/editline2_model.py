@@ -68,6 +68,16 @@ class EditLine2Model(torch.nn.Module):
         data["edgegt"] = data["edgegt"].to(dev) if "edgegt" in data else data["mask"]
         return data["image"], data["gt"], data["mask"], data["edgegt"], None
 
+    def _mode_for(self, B, H, W, low_latency):
+        """Execution mode of a call of B images when the caller did not pin it: the mode a FULL batch (--batchSize) of this
+        size would take.  test.py --batchSize 8 over 20 files runs batches of 8, 8, 4; chosen from the call's own size the
+        last one would cross LOW_LATENCY_MAX_PIXELS into the other mode (other kernels: fp32-rounding differences, possibly
+        another hard-mask pixel) -- an image's result must not depend on where the file list ends."""
+        if low_latency is not None:
+            return bool(low_latency)
+        full = max(int(B), int(getattr(self.opt, "batchSize", 1) or 1))
+        return _lib.Engine.is_low_latency(full, H, W)
+
     def inference_u8(self, data):
         """mode='inference' followed by test.py:25-27 -- `((generated + 1) / 2 * 255).astype(uint8)` in HWC order and
         `(mask * 255).astype(uint8)` -- as ONE library call: the quantisation is fused into the forward's last kernel, so
@@ -77,11 +87,12 @@ class EditLine2Model(torch.nn.Module):
             raise NotImplementedError("call model.eval() first: only the eval branch of generate_fake exists here")
         eng = self.engine()
         with torch.no_grad():
-            return eng.inference_u8(inputs.float().contiguous(), line.float().contiguous(), _lib.flags_from_opt(self.opt))
+            return eng.inference_u8(inputs.float().contiguous(), line.float().contiguous(), _lib.flags_from_opt(self.opt),
+                                    low_latency=self._mode_for(inputs.shape[0], inputs.shape[2], inputs.shape[3], None))
 
     def forward(self, data, mode, low_latency=None):
-        """`low_latency` (no reference counterpart): None = the Engine picks the execution mode from the call's size,
-        True / False = pinned.  Results are bit-identical across batch compositions only WITHIN one mode
+        """`low_latency` (no reference counterpart): None = the execution mode of a full --batchSize batch of this image size
+        (_mode_for: a ragged last batch runs in the mode of the full ones), True / False = pinned.  Results are bit-identical across batch compositions only WITHIN one mode
         (include/sketchedit_hip.h), so callers whose batch size varies per request (serve.BatchingServer,
         shard.sharded_inference) pin it."""
         inputs, real_image, line, line_full, _ = self.preprocess_input(data)
@@ -93,7 +104,8 @@ class EditLine2Model(torch.nn.Module):
         flags = _lib.flags_from_opt(self.opt)
         with torch.no_grad():
             r = eng.inference(inputs.float().contiguous(), line.float().contiguous(), flags,
-                              visualize=(mode == "visualize"), low_latency=low_latency)
+                              visualize=(mode == "visualize"),
+                              low_latency=self._mode_for(inputs.shape[0], inputs.shape[2], inputs.shape[3], low_latency))
         if mode == "inference":
             return r["composed"], r["mask"]
         return {"mask": r["hard"], "maskim": r["maskim"], "coarse": r["coarse"], "fine": r["fine"],

@@ -1,6 +1,7 @@
 """GPU tests of the host-side mirror: models.create_model(opt)(data, mode=...) and the per-op modules,
 used the way the reference's test.py / demo.py use theirs."""
 import os
+import shutil
 
 import numpy as np
 import pytest
@@ -275,6 +276,78 @@ def test_celeb_sample_through_test_py_matches_the_reference(tmp_path, golden_dir
     assert int((vis["mask"].cpu().numpy()[0, 0] != hard).sum()) == 0, "hard-mask flips on the bundled face"
     d = np.abs(out.astype(int) - g["composed_u8"].astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def _run_test_py(argv):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_test_script_ckpt", os.path.join(root, "test.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(argv)
+
+
+def test_test_celeb_sh_with_checkpoint_files_on_disk(tmp_path, golden_dir):
+    """test.py exactly as /root/reference/test_celeb.sh:1-17 runs it -- NO --synthetic_weights: the weights come from
+    <checkpoints_dir>/<name>/latest_net_{G,M}.pth through util.load_network (/root/reference/util/util.py:214-225,
+    models/editline2_model.py:195-197) -> load_state_dict -> .cuda() -> se_load_weights.  One file is a plain state dict,
+    the other carries DataParallel's 'module.' prefix (:221-222).  Inputs: the four bundled faces of
+    datasets/face_release/list.txt, written back to PNG files from the fixtures; outputs against the REFERENCE's PNGs."""
+    from PIL import Image
+    from digest_util import crop_boxes
+    ck = tmp_path / "checkpoints" / "celeb"
+    os.makedirs(ck)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()}, ck / "latest_net_G.pth")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()}, ck / "latest_net_M.pth")
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    g0 = dict(np.load(os.path.join(golden_dir, "c1_face.npz")))
+    Image.fromarray(g0["image_u8"]).save(tmp_path / "images" / "602.png")
+    Image.fromarray(g0["sketch_u8"]).save(tmp_path / "edges" / "602.png")
+    others = {sid: dict(np.load(os.path.join(golden_dir, "sample_%s.npz" % sid))) for sid in ("822", "873", "902")}
+    for sid, g in others.items():
+        (tmp_path / "images" / (sid + ".png")).write_bytes(g["image_png"].tobytes())
+        (tmp_path / "edges" / (sid + ".png")).write_bytes(g["sketch_png"].tobytes())
+    (tmp_path / "list.txt").write_text("602.png\n822.png\n873.png\n902.png\n")
+    base = ("--nThreads 1 --name celeb --joint_train_inp --dataset_mode testimage --image_dirs {d}/images --mask_dirs {d}/edges "
+            "--image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 --netG deepfillc2 --pool_type max "
+            "--use_cam --which_epoch latest --checkpoints_dir {d}/checkpoints").format(d=tmp_path)
+
+    def check(outdir):
+        out = np.asarray(Image.open(outdir / "602.png"))
+        d = np.abs(out.astype(int) - g0["composed_u8"].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+        for sid, g in others.items():
+            out = np.asarray(Image.open(outdir / (sid + ".png")))
+            assert out.shape == (256, 256, 3)
+            for i, (t, l) in enumerate(crop_boxes(256, 256)):
+                d = np.abs(out[t:t + 64, l:l + 64].astype(int) - g["composed_u8_crops"][i].astype(int))
+                assert d.max() <= 1 and (d > 0).mean() < 0.01, (sid, i)
+
+    _run_test_py((base + " --batchSize 1 --output_dir {d}/results".format(d=tmp_path)).split())       # test_celeb.sh: batch 1
+    check(tmp_path / "results")
+    # a ragged last batch runs in the execution mode of the FULL batches (EditLine2Model._mode_for): --batchSize 5 puts five
+    # 256x256 images above LOW_LATENCY_MAX_PIXELS (default mode); a file list that ends with a batch of two stays in that
+    # mode, so a file's PNG is byte-identical wherever the list ends
+    shutil.copy(tmp_path / "images" / "602.png", tmp_path / "images" / "602b.png")
+    shutil.copy(tmp_path / "edges" / "602.png", tmp_path / "edges" / "602b.png")
+    (tmp_path / "list.txt").write_text("602.png\n822.png\n873.png\n902.png\n602b.png\n873.png\n902.png\n")     # 5 + 2
+    _run_test_py((base + " --batchSize 5 --output_dir {d}/results5".format(d=tmp_path)).split())
+    check(tmp_path / "results5")
+    (tmp_path / "list.txt").write_text("902.png\n873.png\n602.png\n822.png\n602b.png\n")                          # one full batch
+    _run_test_py((base + " --batchSize 5 --output_dir {d}/results5b".format(d=tmp_path)).split())
+    for n in ("602.png", "822.png", "873.png", "902.png"):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "results5" / n)), np.asarray(Image.open(tmp_path / "results5b" / n))), n
+    # the validator of the same directory (tools/check_checkpoint.py): both files would load
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_check_ckpt", os.path.join(root, "tools", "check_checkpoint.py"))
+    cc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cc)
+    assert cc.main([str(ck)]) == 0
+    os.remove(ck / "latest_net_M.pth")
+    with pytest.raises((FileNotFoundError, OSError, RuntimeError)):
+        _run_test_py((base + " --batchSize 1 --output_dir {d}/results4".format(d=tmp_path)).split())
 
 
 def test_module_prefixed_checkpoint_through_the_c_abi(golden_dir):

@@ -315,6 +315,14 @@ def test_execution_mode_is_pinned_where_batch_composition_varies():
     shard.sharded_inference(fwd, torch.zeros(4, 3, 256, 256), torch.zeros(4, 1, 256, 256))
     assert seen == [False, True]
     assert shard.global_mode(8, 256, 256) is False and shard.global_mode(1, 512, 512) is True
+    # EditLine2Model (test.py): the mode of a FULL --batchSize batch, so a ragged last batch does not change kernels
+    from types import SimpleNamespace
+    from sketchedit_amd.models.editline2_model import EditLine2Model
+    mf = EditLine2Model._mode_for
+    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=8)), 4, 256, 256, None) is False      # 8, 8, 4: all default mode
+    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=1)), 1, 256, 256, None) is True       # test_celeb.sh
+    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=1)), 32, 256, 256, None) is False     # a caller's own big batch
+    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=8)), 4, 256, 256, True) is True       # pinned wins
 
 
 def test_check_checkpoint_missing_key_not_hidden_by_suffix_match(tmp_path):

@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-LABELS = {"wino_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96", "winoup48_kernel": "gconv_n48",
+LABELS = {"wino_kernel": "wino_n192", "wino24_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96", "winoup48_kernel": "gconv_n48",
                  "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96", "gconv_kernel<3": "gconv_n48", "gconv_kernel<2": "gconv_n24",
                  "rtile_kernel<3": "gconv_n48", "rtile_kernel<2": "gconv_n24", "rconv16": "gconv_n192", "rconv96": "gconv_n96",
                  "att2_pair_kernel": "att_score", "att2_pv_kernel": "att_pv", "att2_softmax": "att_softmax", "att2_stats": "att_softmax",
