@@ -141,6 +141,91 @@ def pmc_traffic(argv_child, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def parse_cpulist(text):
+    """'0-63,128-191' -> [0..63, 128..191] (the format of /sys/devices/system/node/node*/cpulist)"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpu_core_key(c):
+    """(package, core, cpu) of logical CPU c from sysfs, so that a sorted pool keeps SMT siblings adjacent and a contiguous
+    slice owns whole cores; (0, c, c) where sysfs does not say"""
+    try:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        with open(base + "physical_package_id") as f:
+            pk = int(f.read())
+        with open(base + "core_id") as f:
+            return (pk, int(f.read()), c)
+    except (OSError, ValueError):
+        return (0, c, c)
+
+
+def rank_cpu_slice(local_rank, local_world, allowed, node_cpus=None, node_peers=None, key=None):
+    """CPUs rank `local_rank` of `local_world` ranks on this host pins itself to (host threads of a rank: weight packing,
+    the launch loop, the oracle legs of rank 0).
+      * the GPU's NUMA node is known (node_cpus = that node's CPUs, node_peers = sorted local ranks whose GPU sits on the
+        same node): the node's allowed CPUs are divided among those ranks -- host memory and the launch thread stay on the
+        socket the GPU hangs off;
+      * unknown: a contiguous 1/local_world slice of the allowed CPUs.
+    Never empty: falls back to every allowed CPU."""
+    allowed = sorted(allowed, key=key)
+    pool, idx, cnt = allowed, local_rank, local_world
+    if node_cpus and node_peers and local_rank in node_peers:
+        on_node = [c for c in allowed if c in set(node_cpus)]
+        if len(on_node) >= len(node_peers):
+            pool, idx, cnt = on_node, node_peers.index(local_rank), len(node_peers)
+    per = len(pool) // max(cnt, 1)
+    sl = pool[idx * per:(idx + 1) * per] if per >= 1 else []
+    return sorted(sl or allowed)
+
+
+def gpu_numa_cpus(dev_index):
+    """CPUs of the NUMA node GPU `dev_index` is attached to (sysfs, through its PCI address), or None"""
+    try:
+        bdf = torch.cuda.get_device_properties(dev_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id") else None
+        if bdf is None:
+            p = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % str(bdf).lower()) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            return node, parse_cpulist(f.read())
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None, None
+
+
+def pin_rank(local_rank, local_world, dev_index):
+    """Per-rank host placement: CPU affinity next to the rank's GPU and a thread budget to match, so that
+    eight ranks' weight packing / oracle legs do not oversubscribe the host (oneDNN collapses when they do, tools/cpu_probe.py).
+    HIP_VISIBLE_DEVICES policy: NOT narrowed per rank -- every rank sees every GPU and selects LOCAL_RANK with
+    torch.cuda.set_device (RCCL's peer-to-peer transport over xGMI needs the peers visible); a caller-set
+    HIP_VISIBLE_DEVICES is honoured, LOCAL_RANK then indexes the visible list.  Returns a description for the JSON line."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return {"affinity": None}
+    node, cpus = gpu_numa_cpus(dev_index)
+    peers = None
+    if cpus is not None and local_world > 1:
+        peers = [r for r in range(local_world) if gpu_numa_cpus(r)[0] == node] if torch.cuda.device_count() >= local_world else None
+    sl = rank_cpu_slice(local_rank, local_world, allowed, cpus, peers, key=cpu_core_key) if local_world > 1 else sorted(allowed)
+    try:
+        os.sched_setaffinity(0, sl)
+    except OSError:
+        return {"affinity": None}
+    threads = max(1, min(32, len(sl)))
+    torch.set_num_threads(threads)
+    return {"affinity": "%d CPUs (%d..%d)" % (len(sl), sl[0], sl[-1]), "numa_node": node, "threads": threads,
+            "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: this process becomes the launcher of N rank processes running this
     very command line (one per GPU, the environment torch.distributed.run would give them) and relays rank 0's stdout.
@@ -308,7 +393,10 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
+    placement = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), dev_index)
 
+    if os.environ.get("SE_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: a rank that dies after the rendezvous
+        raise SystemExit(3)
     B, S = args.batch, args.size
     eng = Engine(dev_index)
     eng.load_state_dict("M", synth.make_state_dict("M", 0))
@@ -514,6 +602,7 @@ def main():
                                    "procedural weights" % (S, S, B),
                        "global_batch": world * B, "size": S, "per_gpu_batch": B,
                        "execution": ("low-latency" if ll_on else "default") + ("+graph" if args.graph else ""),
+                       "host_placement_rank0": placement,
                        "collective": ("one all_gather of the packed (B,4,H,W) outputs per step" +
                                       (" on a side stream, under the next step's forward" if overlap else "") +
                                       ("; NCCL_MAX_NCHANNELS=%s" % os.environ.get("NCCL_MAX_NCHANNELS") if args.backend == "nccl" else "")

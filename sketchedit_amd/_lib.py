@@ -36,30 +36,45 @@ class SketchEditHipError(RuntimeError):
     pass
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, extra_flags=()):
     """hipcc --offload-arch=gfx950 -> sketchedit_amd/lib/libsketchedit_hip.so (cross-compiles without a GPU).
-    One object per source (compiled in parallel, rebuilt only when the source or a header is newer), then one link."""
+    One object per source, compiled in parallel; an object is rebuilt when its source or a header is newer OR when its
+    command line changed (flags / -D macros: the command is kept beside the object), then one link.  The whole build holds
+    an exclusive file lock, so concurrent builders (ranks, test workers) do not write the same objects."""
+    import fcntl
     from concurrent.futures import ThreadPoolExecutor
     hdrs = [os.path.join(CSRC, "se_kernels.h"), os.path.join(CSRC, "se_device.h"), os.path.join(_HERE, "..", "include", "sketchedit_hip.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     objdir = os.path.join(_HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    jobs, objs = [], []
-    for src in SOURCES:
-        sp, op = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
-        objs.append(op)
-        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
-            jobs.append(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", op])
-    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
-        return LIB_PATH
+    with open(os.path.join(_HERE, "lib", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        jobs, objs = [], []
+        for src in SOURCES:
+            sp, op = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(op)
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + list(extra_flags) + ["-c", sp, "-o", op]
+            try:
+                with open(op + ".cmd") as f:
+                    same_cmd = f.read() == " ".join(cmd)
+            except OSError:
+                same_cmd = False
+            if force or not same_cmd or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
+                jobs.append(cmd)
+        if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+            return LIB_PATH
 
-    def run(cmd):
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
-        list(ex.map(run, jobs))
-    run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            if "-c" in cmd:
+                with open(cmd[-1] + ".cmd", "w") as f:
+                    f.write(" ".join(cmd))
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
+            list(ex.map(run, jobs))
+        run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH + ".tmp"] + objs)
+        os.replace(LIB_PATH + ".tmp", LIB_PATH)          # readers never see a half-written library
     return LIB_PATH
 
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -798,17 +799,27 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   if (!wimg || C0 != CG * gran) return 0;
   // dense-K form of the 5x5 first layers (fp32): SE_RTILE_DENSE=0 keeps the channel-padded K
   static const bool dense_on = !(getenv("SE_RTILE_DENSE") && atoi(getenv("SE_RTILE_DENSE")) == 0);
-  if (dense_on && !bf && L.d_wd && L.dense && d.k == 5 && !d.up && L.cfg == GC_N48 && (long long)B * Hin * Win * C0 * 4 < (1ll << 31)) {
-    RTileParams p;
-    memset(&p, 0, sizeof p);
-    p.src = src0; p.wpk = L.d_wd; p.bias = L.d_b; p.dst = dst;
-    p.B = B; p.Hin = Hin; p.Win = Win; p.C = C0; p.G = L.G; p.OH = Ho; p.OW = Wo;
-    p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
-    p.act = d.act; p.xcd = xcd_remap_enabled(); p.dense = L.dense; p.nch = L.nchd; p.NP = 48;
-    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 25;
-    set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
-                    2.0 * (double)B * Hin * Win * 48.0 * (4.0 * ((25 * L.dense + 3) / 4)));       // ceil(K / 4) k-steps of 4
-    HIPCHK(c, launch_rtile(p, c->st));
+  if (dense_on && !bf && L.d_wd && L.dense && d.k == 5 && !d.up && L.cfg == GC_N48 && (long long)Hin * Win * C0 * 4 < (1ll << 31)) {
+    // The kernel addresses its source with 32-bit byte offsets.  A batch beyond that range is run as sub-launches of the
+    // SAME kernel form over image ranges (switching to the channel-padded kernel would change the summation
+    // order, i.e. the bit-identity of an image's result across batch compositions within one execution mode).
+    const long long per_img = (long long)Hin * Win * C0 * 4;
+    const char* lim_env = getenv("SE_TEST_OFFSET_LIMIT");       // test aid: a smaller byte range forces the sub-launches (read per call)
+    const long long lim = lim_env ? atoll(lim_env) : (1ll << 31);
+    const int bmax = (int)std::max<long long>(1, (lim - 1) / per_img);
+    for (int b0 = 0; b0 < B; b0 += bmax) {
+      const int nb = std::min(bmax, B - b0);
+      RTileParams p;
+      memset(&p, 0, sizeof p);
+      p.src = src0 + (size_t)b0 * Hin * Win * C0; p.wpk = L.d_wd; p.bias = L.d_b; p.dst = dst + (size_t)b0 * Ho * Wo * L.G;
+      p.B = nb; p.Hin = Hin; p.Win = Win; p.C = C0; p.G = L.G; p.OH = Ho; p.OW = Wo;
+      p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
+      p.act = d.act; p.xcd = xcd_remap_enabled(); p.dense = L.dense; p.nch = L.nchd; p.NP = 48;
+      const double alg = 2.0 * (double)nb * Ho * Wo * d.cout * d.cin * 25;
+      set_launch_cost(alg, 4.0 * ((double)nb * Hin * Win * d.cin + (double)nb * Ho * Wo * (d.cout / 2)), d.name,
+                      2.0 * (double)nb * Hin * Win * 48.0 * (4.0 * ((25 * L.dense + 3) / 4)));       // ceil(K / 4) k-steps of 4
+      HIPCHK(c, launch_rtile(p, c->st));
+    }
     *done = true;
     return 0;
   }

@@ -1137,6 +1137,11 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
   p.Pt = fused ? p.P : p.E;
   {
     const long n = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);
+    // Preconditions of the fused streaming pass: its column shifts read up to wc + 8 floats in front of / behind
+    // E and the key tables without a clamp, so the guard bands must be that wide, and att2_prep_kernel fills them from its
+    // threads idx < guard -- the launch below must have at least `guard` threads.  (E's pad columns are written by the E
+    // GEMM itself as finite values; an unguarded read is multiplied by kmul = 0, which only a finite value survives.)
+    if (p.guard < p.wc + 8 || ((n + 255) / 256) * 256 < (long)p.guard) return hipErrorInvalidValue;
     ProfScope ps_(st, PL_ATT_PREP);
     hipLaunchKernelGGL(att2_prep_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(att2_transpose_kernel<BF16>, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);

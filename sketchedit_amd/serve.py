@@ -101,11 +101,11 @@ class BatchingServer:
         self._has_knob = [_accepts_low_latency(m) for m in self.models]
         self.max_batch, self.max_wait_s = max_batch, max_wait_s
         self._lock = threading.Condition()
-        self._queue = []          # (x, m, size_raw, slot)
+        self._queue = []          # (x, m, size_raw, slot, arrival time)
         self._stop = False
         self.batches = []         # sizes of the batches that were run (observability / tests)
         self.batches_by_model = [0] * len(self.models)
-        self._collecting = False  # one worker at a time waits out a group's deadline; the others block on the condition
+        self._collecting = set()  # working sizes some worker is waiting out a deadline for (one collector per size)
         self._workers = [threading.Thread(target=self._run, args=(k,), daemon=True) for k in range(len(self.models))]
         for t in self._workers:
             t.start()
@@ -116,7 +116,7 @@ class BatchingServer:
         with self._lock:
             if self._stop:
                 raise RuntimeError("server is closed")
-            self._queue.append((x, m, size_raw, slot))
+            self._queue.append((x, m, size_raw, slot, time.monotonic()))
             self._lock.notify_all()
         slot["done"].wait()
         if slot["err"] is not None:
@@ -131,23 +131,23 @@ class BatchingServer:
             t.join()
 
     def _take_group(self):
-        """Oldest request's size decides the group; wait briefly for more requests of that size.  Only ONE worker at a
-        time is the collector (the others sleep on the condition until it has taken its group), and the collector
-        re-reads the head of the queue after every wake-up, so no worker waits out a deadline for a stale shape while
-        requests of another shape are queued and its GPU is idle."""
+        """A worker becomes the collector of the OLDEST queued request whose working size no other worker is collecting, and
+        waits for company of that size until the group is full or `max_wait_s` after that oldest request ARRIVED (not after
+        collection started).  Several workers collect at once, one per distinct size, so an idle GPU never sits out a
+        deadline for size S1 while requests of size S2 are queued; with k sizes queued the waits overlap
+        instead of stacking."""
         with self._lock:
             while True:
-                while (not self._queue or self._collecting) and not self._stop:
-                    self._lock.wait()
-                if not self._queue:
-                    return None                       # stopped and drained
-                if self._collecting:                  # stopping: let the collector finish its group first
-                    self._lock.wait(0.001)
+                head = next((q for q in self._queue if tuple(q[0].shape) not in self._collecting), None)
+                if head is None:
+                    if self._stop and not self._queue:
+                        return None                   # stopped and drained
+                    self._lock.wait(0.05 if self._stop else None)
                     continue
-                self._collecting = True
+                shape = tuple(head[0].shape)
+                self._collecting.add(shape)
                 try:
-                    shape = tuple(self._queue[0][0].shape)
-                    deadline = time.monotonic() + self.max_wait_s
+                    deadline = head[4] + self.max_wait_s
                     while True:
                         n = sum(1 for q in self._queue if tuple(q[0].shape) == shape)
                         left = deadline - time.monotonic()
@@ -158,8 +158,8 @@ class BatchingServer:
                     taken = {id(q) for q in group}    # (list.remove would compare the tensors inside the tuples)
                     self._queue = [q for q in self._queue if id(q) not in taken]
                 finally:
-                    self._collecting = False
-                    self._lock.notify_all()           # the next collector may start on what is left
+                    self._collecting.discard(shape)
+                    self._lock.notify_all()           # requests of this size that did not fit may be collected now
                 return group
 
     def _mode(self, shape):

@@ -76,3 +76,33 @@ def test_bench_self_launch_propagates_a_rank_failure():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
     assert r.returncode != 0 and not r.stdout.strip()
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_share_the_gpu_over_gloo():
+    """The world-8 shape of BASELINE config 4 (256x256 batch 256 over 8 GPUs) with what a 1-GPU box offers: eight rank
+    processes started by bench.py itself, all on cuda:0, exchanging over gloo, at 64x64 -- rank bookkeeping (every rank
+    generates rows rank*B .. of the global batch), the order of the gathered shards (--check-gather: every rank finds its own
+    rows at its own offset, rank 0 recomputes image 0 of the LAST rank's shard bit for bit), the max-over-ranks clock, the
+    per-rank CPU slices.  RCCL itself has never run with more than one rank here: no scaling curve."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--device", "0",
+           "--check-gather", "--no-parity"] + SMALL
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["per_gpu_batch"] == 2
+    assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    pl = d["config"]["host_placement_rank0"]
+    assert pl and pl.get("threads", 0) >= 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_propagate_a_late_rank_failure():
+    """World 8, the LAST rank fails (SE_BENCH_FAIL_RANK, a test hook read after the process group is up): the job ends with a
+    non-zero code and no JSON line instead of seven ranks waiting in a collective."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--device", "0", "--no-parity"] + SMALL
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SE_BENCH_FAIL_RANK"] = "7"
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode != 0 and not r.stdout.strip()

@@ -303,6 +303,20 @@ def test_op_first_layer_dense_k_vs_oracle(eng, case, monkeypatch):
     assert _md(y2, ref) < TOL_OP
 
 
+def test_op_first_layer_dense_k_oversized_batch_keeps_the_kernel_form(eng, monkeypatch):
+    """a batch whose first-layer input exceeds the kernel's 32-bit byte offsets runs as sub-launches of the SAME
+    dense-K kernel (not the channel-padded one, which sums in another order): forced here with a small byte limit
+    (SE_TEST_OFFSET_LIMIT), the result is bit-identical to the single launch."""
+    a = 1.5 / np.sqrt(5 * 25)
+    w = synth.uniform(61, "dk.w", (48, 5, 5, 5), -a, a)
+    b = synth.uniform(61, "dk.b", (48,), -0.3, 0.3)
+    x = synth.uniform(61, "dk.x", (5, 5, 24, 40), -1, 1)
+    y1 = eng.gated_conv2d(_cuda(x), w, b)
+    monkeypatch.setenv("SE_TEST_OFFSET_LIMIT", str(2 * 24 * 40 * 8 * 4 + 1))      # two images (stored NHWC8) per sub-launch: 2 + 2 + 1
+    y2 = eng.gated_conv2d(_cuda(x), w, b)
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
 def test_op_attention_soft_scores_vs_oracle(eng, shape):
     """Small activations keep the softmax far from one-hot (10 * <q, k> of order 1), so a wrong pairing of pixels in

@@ -274,6 +274,59 @@ def test_batching_server_dispatches_over_several_models():
     assert all(f.calls > 0 for f in fakes), [f.calls for f in fakes]
 
 
+def test_batching_server_collects_distinct_sizes_concurrently():
+    """with requests of two working sizes queued and two workers, both groups are collected at once (one
+    collector per size, deadline counted from the request's ARRIVAL): the waits overlap instead of stacking."""
+    import threading
+    import time
+    from PIL import Image
+    from sketchedit_amd import serve
+
+    class Fake:
+        def __call__(self, data, mode):
+            return data["image"], data["mask"]
+
+    wait = 0.4
+    srv = serve.BatchingServer(models=[Fake(), Fake(), Fake()], max_batch=8, max_wait_s=wait)
+    sizes = [(64, 64), (64, 128), (128, 64)]
+    done = {}
+
+    def worker(k):
+        t0 = time.monotonic()
+        srv.submit(Image.new("RGB", sizes[k]), Image.new("L", sizes[k]))
+        done[k] = time.monotonic() - t0
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    srv.close()
+    assert sorted(srv.batches) == [1, 1, 1]
+    # every lone request waits out ITS deadline once (~0.4 s); stacked collection would make the last one wait ~1.2 s
+    assert max(done.values()) < 2 * wait, done
+    assert min(done.values()) >= 0.9 * wait, done
+
+
+def test_rank_cpu_slices_for_multi_gpu_launch():
+    """bench.py's per-rank host placement: disjoint CPU slices that cover whole cores, on the GPU's NUMA
+    node when sysfs names it; never empty."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("se_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_cpulist("0-3,8-9,12\n") == [0, 1, 2, 3, 8, 9, 12]
+    allowed = set(range(256))
+    sl = [bench.rank_cpu_slice(r, 8, allowed) for r in range(8)]
+    assert all(len(x) == 32 for x in sl) and len(set().union(*map(set, sl))) == 256      # disjoint, complete
+    # a 2 x 64-core host with SMT: logical CPUs c and c + 128 share a core; GPUs 0-3 on node 0
+    key = lambda c: (c // 64 % 2, c % 64, c)         # noqa: E731
+    node0 = bench.parse_cpulist("0-63,128-191")
+    s2 = bench.rank_cpu_slice(2, 8, allowed, node0, [0, 1, 2, 3], key=key)
+    assert len(s2) == 32 and set(s2) <= set(node0) and all((c + 128) % 256 in s2 or (c - 128) in s2 for c in s2)   # whole cores
+    s0 = bench.rank_cpu_slice(0, 8, allowed, node0, [0, 1, 2, 3], key=key)
+    assert not set(s0) & set(s2)
+    assert bench.rank_cpu_slice(0, 1, {3, 4}) == [3, 4]
+    assert bench.rank_cpu_slice(5, 8, {0, 1}) == [0, 1]                                   # fewer CPUs than ranks: everything
+
+
 def test_execution_mode_is_pinned_where_batch_composition_varies():
     """the library's results are bit-identical across batch positions only within one execution mode,
     so the callers whose batch size varies pin the mode: BatchingServer from (max_batch, working size) -- never from the
