@@ -269,6 +269,16 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
   // trace showed both waves of a SIMD idle ~150 of 2200 cycles per iteration in that wait)
   // The raw loads are ordinary loads that hipcc tracks itself (se_wino.hip); the W DMA is hidden from it, so its own wait
   // in front of the transform is a vmcnt(0) as well.
+  // What bounds the kernel (round 4, same-box ablations with tools/ab_variants.sh, 33 launches = 4.65 ms): the MFMA stream
+  // is 67 % of a launch, but with the MFMAs REMOVED (folds cut, dead-code eliminated) the skeleton -- W DMA, raw gathers,
+  // transform, barriers, epilogue -- still takes 3.50 ms: the vector-memory path is the longer pole and the two overlap only
+  // partly (a wave in front of a full vector-memory queue issues no MFMAs either).  Removing one ingredient at a time:
+  // barriers (2 of 3) -1.6 %, activation arithmetic of the epilogue -1.0 %, two thirds of the fold arithmetic -1.7 %,
+  // transform arithmetic + X writes -7 %, all W DMA -4 %, all raw gathers -9 %.  Per OUTPUT the kernel moves what
+  // se_wino.hip moves through the vector-memory path (W: 6.75 instead of 4.5 KB -- 32-tile workgroups; raw: 3.75 instead of
+  // 6 KB) for 25 % fewer MFMAs, so it sits at the crossover of the two bounds.  Tried and not faster: all ten raw pieces of a
+  // task in the 3/4 iteration after the transform (more lead time: +1.7 % -- it is the queue, not the latency), `nt` gathers
+  // (+4 %: raw lines ARE re-read from L2), sc0 / sc1 gathers (no change).
   // ---- prologue: W slots 0..3; X sub-stage 0 transformed; raw pieces of sub-stage 1 in flight in r
   set_offs(0);
 #pragma unroll
