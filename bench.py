@@ -101,6 +101,9 @@ def cpu_baseline(budget_s=25.0):
             "samples": samples}
 
 
+TRACE_US = {}      # label -> {"avg_us", "launches"} from the rocprofv3 --kernel-trace child pass (filled by pmc_traffic)
+
+
 def pmc_traffic(argv_child, timeout_s=240):
     """HBM bytes per launch and kernel label from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit
     one pass: MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a 1-step child run of this script.  FETCH_SIZE is doubled
@@ -113,6 +116,22 @@ def pmc_traffic(argv_child, timeout_s=240):
     out = {}
     tmp = tempfile.mkdtemp(prefix="se_pmc_", dir="/tmp")
     try:
+        # pass 0: --kernel-trace alone -> average launch duration per label WITHOUT the in-library event pairs (which cost the
+        # first launch after a different kernel ~50 us at 256x256 batch 32: the events' own cache maintenance)
+        d = os.path.join(tmp, "trace")
+        cmd = [exe, "--kernel-trace", "-d", d, "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py")] + argv_child
+        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if p.returncode == 0 and files:
+            dur = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    k = r["Kernel_Name"].split("(")[0].replace("void se::", "").replace("se::", "")
+                    lab = next((v for pre, v in KERNEL_LABELS.items() if k.startswith(pre)), None)
+                    if lab:
+                        dur.setdefault(lab, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            TRACE_US.clear()
+            TRACE_US.update({lab: {"avg_us": round(sum(v) / len(v), 2), "launches": len(v)} for lab, v in dur.items()})
         for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable,
@@ -539,11 +558,16 @@ def main():
                                                   max(sum(r["total_ms"] for r in mfma), 1e-9), 3)}
         if world == 1 and not args.no_traffic and not args.force_dist:
             child = ["--steps", "1", "--warmup", "1", "--size", str(S), "--batch", str(B), "--dtype", args.dtype,
-                     "--low-latency", args.low_latency, "--no-cpu-baseline", "--no-parity", "--no-traffic"]
+                     "--low-latency", args.low_latency, "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-secondary"]
             tr, src = pmc_traffic(child)
             roofline["traffic"] = tr.get(dom["kernel"]) if tr else None
             roofline["traffic_source"] = src
             roofline["traffic_all"] = tr
+            t_us = TRACE_US.get(dom["kernel"])
+            if t_us:     # the same figure from the rocprofv3 --kernel-trace child run (no event pairs around the launches)
+                roofline["rocprofv3_avg_launch_us"] = t_us["avg_us"]
+                roofline["rocprofv3_frac"] = round(dom["flops_executed"] / dom["launches"] / (t_us["avg_us"] * 1e-6) / 1e12 / peak, 4)
+                roofline["rocprofv3_all"] = dict(TRACE_US)
 
     # ---- parity of this very run against the oracle on image 0 (CPU, rank 0)
     parity = None

@@ -1017,7 +1017,13 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     // feeds the 0.5 threshold).  Read per call: the tests compare both forms in one process.
     const char* f43_env = getenv("SE_WINOGRAD_F43");
     const int f43_mode = f43_env ? atoi(f43_env) : 1;
-    const bool f43 = (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
+    const char* f43_skip = getenv("SE_WINOGRAD_F43_SKIP");      // developer aid: comma-separated layer names that keep F(2x2,3x3)
+    bool skip_this = false;
+    if (f43_skip) {
+      std::string sk = std::string(",") + f43_skip + ",";
+      skip_this = sk.find(std::string(",") + d.name + ",") != std::string::npos;
+    }
+    const bool f43 = !skip_this && (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = f43 ? Win / 4 : Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();

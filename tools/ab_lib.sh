@@ -2,7 +2,7 @@
 # same-box A/B of two builds of the library: tools/_build/lib_prev.so (SKETCHEDIT_HIP_LIB) against the in-tree one, alternating
 #   usage: tools/ab_lib.sh [bench args...]
 root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root
-Q="--no-cpu-baseline --no-parity --no-traffic --steps 40"
+Q="--no-cpu-baseline --no-parity --no-traffic --no-secondary --steps 40"
 for rep in 1 2 3; do
   for v in prev new; do
     if [ $v == prev ]; then export SKETCHEDIT_HIP_LIB=$root/tools/_build/lib_prev.so; else unset SKETCHEDIT_HIP_LIB; fi

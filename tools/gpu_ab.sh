@@ -8,7 +8,7 @@ for a in "$@"; do case $a in c3|c5|b1|noc2) cfgs="$cfgs $a";; *=*) export "$a";;
 if [ "$kexpr" != "-" ]; then
   timeout 1200 python -m pytest tests -m gpu -q --tb=short -x -k "$kexpr" > $out/pytest.log 2>&1; tail -n 12 $out/pytest.log
 fi
-Q="--no-cpu-baseline --no-parity --no-traffic"
+Q="--no-cpu-baseline --no-parity --no-traffic --no-secondary"
 for c in $cfgs; do
   case $c in
     c2) [[ "$cfgs" == *noc2* ]] || python bench.py $Q --steps 30 > $out/c2.json 2>$out/c2.err ;;

@@ -15,7 +15,7 @@ else
 fi
 tail -n 40 $out/pytest.log
 if [ "$3" == "nobench" ]; then exit 0; fi
-Q="--no-cpu-baseline --no-parity --no-traffic"
+Q="--no-cpu-baseline --no-parity --no-traffic --no-secondary"
 # batch-1 latency: round-1 kernels (SE_ATT_V1 patch-form attention, default launch shapes) vs the low-latency mode
 SE_ATT_V1=1 timeout 300 python bench.py --batch 1 --low-latency off $Q --steps 30 > $out/b1_256_r01.json 2> $out/b1_256_r01.err
 timeout 300 python bench.py --batch 1 --low-latency off $Q --steps 30 > $out/b1_256_default.json 2> $out/b1_256_default.err

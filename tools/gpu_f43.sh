@@ -4,7 +4,7 @@
 tag=${1:-f43}; kexpr=${2:-winograd}; reps=${3:-2}
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out/$tag; mkdir -p $out; cd $root
 timeout 600 python -m pytest tests -m gpu -q --tb=short -k "$kexpr" > $out/pytest.log 2>&1; tail -n 25 $out/pytest.log
-Q="--no-cpu-baseline --no-traffic --steps 30"
+Q="--no-cpu-baseline --no-traffic --no-secondary --steps 30"
 for rep in $(seq $reps); do
   for v in 0 1; do
     SE_WINOGRAD_F43=$v timeout 300 python bench.py $Q > $out/c2_f43_${v}_$rep.json 2> $out/c2_f43_${v}_$rep.err

@@ -4,7 +4,7 @@
 tag=$1; kexpr=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out/$tag; mkdir -p $out; cd $root
 timeout 900 python -m pytest tests -m gpu -q --tb=short -k "$kexpr" > $out/pytest.log 2>&1; tail -n 15 $out/pytest.log
-Q="--no-cpu-baseline --no-parity --no-traffic"
+Q="--no-cpu-baseline --no-parity --no-traffic --no-secondary"
 python bench.py $Q > $out/c2.json 2>$out/c2.err
 python bench.py --size 512 --batch 8 $Q --steps 20 > $out/c3.json 2>$out/c3.err
 python bench.py --dtype bf16 --size 512 --batch 16 $Q --steps 20 > $out/c5.json 2>$out/c5.err

@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-parity --no-traffic"
+Q="--no-cpu-baseline --no-parity --no-traffic --no-secondary"
 profile() {   # name, bench args
   name=$1; shift
   cd /tmp
