@@ -278,7 +278,10 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
   // se_wino.hip moves through the vector-memory path (W: 6.75 instead of 4.5 KB -- 32-tile workgroups; raw: 3.75 instead of
   // 6 KB) for 25 % fewer MFMAs, so it sits at the crossover of the two bounds.  Tried and not faster: all ten raw pieces of a
   // task in the 3/4 iteration after the transform (more lead time: +1.7 % -- it is the queue, not the latency), `nt` gathers
-  // (+4 %: raw lines ARE re-read from L2), sc0 / sc1 gathers (no change).
+  // (+4 %: raw lines ARE re-read from L2), sc0 / sc1 gathers (no change); 16-byte gathers with the five columns of a task
+  // split over lanes l / l + 32 (role A: c0, c2, c4; role B: c1, c3; six gathers per wave instead of ten, the halves of the
+  // column transform exchanged with v_permlane32_swap: parity green, 256 VGPRs, +390 VALU instructions per wave for the
+  // exchange and the per-lane signs: +1.6 %).
   // ---- prologue: W slots 0..3; X sub-stage 0 transformed; raw pieces of sub-stage 1 in flight in r
   set_offs(0);
 #pragma unroll
