@@ -285,6 +285,7 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   L.cfg = cfg; L.NP = NP; L.nch = nch; L.G = G; L.CGp = Cp / 4; L.T = T;
   L.packed = true;
   if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
+  if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 48 && d.cout == 192 && d.act != ACT_NONE && Cp == d.cin) return pack_wino24(c, L);      // xconv5
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
   if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
   if (winoup48_eligible_layer(d) && Cp == d.cin) return pack_winoup48(c, L);
@@ -527,13 +528,15 @@ int pack_wino24(se_ctx* c, Layer& L) {
   const int NP = 192;
   // two images for the two-source layers: the first source alone (vector source folded into a bias: conv11) and both
   // sources (allconv11: 6 chunks per position)
-  for (int nchk = 3; nchk <= d.cin / 32; nchk += 3) {
+  // (a 48-channel layer -- xconv5 -- has one image of 2 chunks per position, the second half empty)
+  const int nchk_first = d.cin == 48 ? 2 : 3, nchk_last = d.cin == 48 ? 2 : d.cin / 32;
+  for (int nchk = nchk_first; nchk <= nchk_last; nchk += 3) {
   std::vector<float> img((size_t)24 * nchk * NP * 32, 0.f), bias(NP, 0.f);
   for (int n = 0; n < NP; ++n) {
     const int t = n / 16, r = n % 16;
     const int oc = r < 8 ? t * 8 + r : 96 + t * 8 + (r - 8);
     bias[n] = L.b[oc];
-    for (int ic = 0; ic < nchk * 32; ++ic) {
+    for (int ic = 0; ic < nchk * 32 && ic < d.cin; ++ic) {
       const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
       double tt[4][3];
       for (int i = 0; i < 4; ++i)
@@ -550,11 +553,11 @@ int pack_wino24(se_ctx* c, Layer& L) {
           }
     }
   }
-  float*& du = nchk == 3 ? L.d_u24 : L.d_u24b;
+  float*& du = nchk <= 3 ? L.d_u24 : L.d_u24b;
   if (du) (void)hipFree(du);
   HIPCHK(c, hipMalloc(&du, img.size() * 4));
   HIPCHK(c, hipMemcpy(du, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-  if (nchk == 3) {
+  if (nchk <= 3) {
     if (L.d_ub24) (void)hipFree(L.d_ub24);
     HIPCHK(c, hipMalloc(&L.d_ub24, bias.size() * 4));
     HIPCHK(c, hipMemcpy(L.d_ub24, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
@@ -1043,6 +1046,27 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 96, d.name, alg * 16.0 / 36.0 * (folded ? 0.5 : 1.0));
     HIPCHK(c, launch_wino(wp, c->st));
     return 0;
+  }
+  // 48 -> 192 (xconv5 of netG) on the hybrid kernel's 48-channel instantiation: 2 chunks per position, the second half empty
+  {
+    const char* f43_env = getenv("SE_WINOGRAD_F43");
+    const int f43_mode = f43_env ? atoi(f43_env) : 1;
+    if (use_wino && f43_mode != 0 && !d.up && !src1 && C0 == 48 && d.cin == 48 && d.cout == 192 && d.stride == 1 && L.d_u24 && L.d_ub24 &&
+        (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (4 * d.rate)) == 0) {
+      WinoParams wp;
+      memset(&wp, 0, sizeof wp);
+      wp.src = src0; wp.upk = L.d_u24; wp.bias = L.d_ub24; wp.dst = dst;
+      wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 4;
+      wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+      wp.xcd = xcd_remap_enabled();
+      udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
+      udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
+      udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
+      const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+      set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * 48 + (double)B * Hin * Win * 96), d.name, alg * 24.0 / 72.0);
+      HIPCHK(c, launch_wino24_c48(wp, c->st));
+      return 0;
+    }
   }
   static const bool use_wino48 = !(getenv("SE_WINOGRAD48") && atoi(getenv("SE_WINOGRAD48")) == 0);
   if (use_wino && use_wino48 && !d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && (long long)B * Hin * Win * 192 < (1ll << 31) &&

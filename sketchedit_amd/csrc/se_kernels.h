@@ -119,6 +119,8 @@ hipError_t launch_vecbias(const float* wv, const float* vec, float* T, int B, in
 // Hybrid F(2,3) x F(4,3) form of the single-source 96 -> 192 layer (se_wino24.hip): 2x4 output tiles, th = h/2, tw = w/4,
 // h % 2d == 0 and w % 4d == 0; upk [72 iterations][192 MIXED rows][32] (pack_wino24), bias [192] MIXED order
 hipError_t launch_wino24(const WinoParams& p, hipStream_t st);
+// the same for a 48-channel source (48 -> 192, xconv5): src NHWC 48, upk [48 iterations][192 MIXED rows][32] (pack_wino24)
+hipError_t launch_wino24_c48(const WinoParams& p, hipStream_t st);
 // 48 -> 96 form (se_wino48.hip): src / dst NHWC 48 channels, upk [24 iterations][96 MIXED rows][32], bias [96] MIXED order
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
 // gen_deconv 96 -> 96 (48 gated), F(2x2,2x2) on the 4 sub-pixel classes (se_wino_up.hip): src NHWC 96 at (h, w), dst NHWC

@@ -81,8 +81,12 @@ DEVFN void static_for(F&& f) {
 
 // NCHK = 32-channel chunks per position: 3 for one 96-channel source, 6 for the two-source layer (allconv11:
 // cat([x_hallu, pm]), editline_g.py:211): chunks 3-5 are gathered from the second tensor
-template <int NCHK>
+// CIN48 (round 4, xconv5 of netG: 48 -> 192): a 48-channel source (192 bytes per pixel), NCHK = 2 chunks per position of
+// which the second carries 16 channels: its iterations issue k-half 0 only (12 MFMAs), its k-half 1 columns of the X tile
+// hold whatever follows the pixel in memory (finite: the next pixel, or the buffer range check's zeros) and are never read.
+template <int NCHK, bool CIN48 = false>
 __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
+  constexpr unsigned PSB = CIN48 ? 192u : 384u;      // bytes per source pixel
   constexpr int TILES = 32;
   constexpr int XB = TILES * 128;      // one X tile: 32 tiles x 32 k
   constexpr int XS = 3 * XB;           // one sub-stage: the X tiles of its three positions
@@ -123,11 +127,11 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d;
       const bool yok = t < p.total_tiles && (unsigned)y < (unsigned)p.h;
-      Ysrc[i * 512 + tid] = yok ? (int)((unsigned)((b * p.h + y) * p.w) * 384u + (unsigned)p16 * 8u) : (int)0x80000000;
+      Ysrc[i * 512 + tid] = yok ? (int)((unsigned)((b * p.h + y) * p.w) * PSB + (unsigned)p16 * 8u) : (int)0x80000000;
     }
     if (p16 < 6) {
       const int x = x0 + (p16 - 1) * p.d;
-      Xsrc[p16 * 32 + srow] = (unsigned)x < (unsigned)p.w ? x * 384 : (int)0x80000000;
+      Xsrc[p16 * 32 + srow] = (unsigned)x < (unsigned)p.w ? x * (int)PSB : (int)0x80000000;
     }
   }
   __syncthreads();
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
       o[1][c] = __builtin_elementwise_add_sat(yb, xc);
     }
   };
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * PSB), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NCHK == 6 ? p.src1 : p.src), 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 384u), 0x00020000);
   f32x2 r[10];          // raw pieces of one task: [row][column]
   auto load_x1 = [&](int chunk, int i) {       // piece i = row * 5 + column: one vector-memory instruction
@@ -316,10 +320,13 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
     constexpr bool more1 = it + 1 < NIT, more4 = it + 4 < NIT;
     constexpr int ls = s + 2;          // sub-stage whose raw pieces are fetched during this one
     constexpr bool ld = ls < NSUB;
+    constexpr bool khalf1 = !(CIN48 && chunk == NCHK - 1);               // (48 channels: the second chunk has k-half 0 only)
     f32x4 wb[3], xb;
-    xb = *(const f32x4*)(Xw + (s % 2) * XS + j * XB + off1);            // k-half 1 fragments of this iteration
+    if (khalf1) {
+      xb = *(const f32x4*)(Xw + (s % 2) * XS + j * XB + off1);          // k-half 1 fragments of this iteration
 #pragma unroll
-    for (int t = 0; t < 3; ++t) wb[t] = *(const f32x4*)(Ww + w0 * WB + t * 2048 + off1);
+      for (int t = 0; t < 3; ++t) wb[t] = *(const f32x4*)(Ww + w0 * WB + t * 2048 + off1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     W24_STAMP_AT(it, 0);
     // one group = 3 MFMAs: k-step e of the three row tiles; `first`: C = 0 (first k-step of a position)
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
     __builtin_amdgcn_sched_barrier(0);
     W24_STAMP_AT(it, 2);
     // vector-memory instructions spread over the MFMA groups (se_wino.hip, point 2)
-    group(wb, xb, 0, false);
+    if (khalf1) group(wb, xb, 0, false);
     if (j == 0 && ld) load_x1(ls % NCHK, 0);
     if (j == 1 && ld) load_x1(ls % NCHK, 7);
     if (j != 2 && more4) dma_w(it + 4, w4, 0);
@@ -369,17 +376,17 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
       for (int t = 0; t < 3; ++t) wa[t] = *(const f32x4*)(Ww + w1 * WB + t * 2048 + off0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    group(wb, xb, 1, false);
+    if (khalf1) group(wb, xb, 1, false);
     if (j == 0 && ld) load_x1(ls % NCHK, 1);
     if (j == 1 && ld) load_x1(ls % NCHK, 8);
     if (j != 2 && more4) dma_w(it + 4, w4, 1);
     __builtin_amdgcn_sched_barrier(0);
-    group(wb, xb, 2, false);
+    if (khalf1) group(wb, xb, 2, false);
     if (j == 0 && ld) load_x1(ls % NCHK, 2);
     if (j == 1 && ld) load_x1(ls % NCHK, 9);
     if (j != 2 && more4) dma_w(it + 4, w4, 2);
     __builtin_amdgcn_sched_barrier(0);
-    group(wb, xb, 3, false);
+    if (khalf1) group(wb, xb, 3, false);
     if (j == 0 && ld) load_x1(ls % NCHK, 3);
     __builtin_amdgcn_sched_barrier(0);
     W24_STAMP_AT(it, 3);
@@ -428,22 +435,23 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
   W24_TRACE_DUMP();
 }
 
-template <int NCHK>
+template <int NCHK, bool CIN48 = false>
 static hipError_t launch_wino24_t(const WinoParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 3 * 32 * 128 + 5 * 192 * 128 + 4 * 512 * 4 + 6 * 32 * 4 + (W24_TRACE_LDS ? 2 * 80 * 8 * 4 : 0);     // X ring 24 KB + W ring 120 KB + source offsets 8.75 KB
   {
-    hipError_t e = ensure_max_lds((const void*)wino24_kernel<NCHK>, LDS);
+    hipError_t e = ensure_max_lds((const void*)wino24_kernel<NCHK, CIN48>, LDS);
     if (e != hipSuccess) return e;
   }
   const int grid = (p.total_tiles + 31) / 32;
   set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_N192);
-  hipLaunchKernelGGL(wino24_kernel<NCHK>, dim3(grid), dim3(512), LDS, st, p);
+  hipLaunchKernelGGL((wino24_kernel<NCHK, CIN48>), dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
 }
 
 hipError_t launch_wino24(const WinoParams& p, hipStream_t st) {
   return p.src1 ? launch_wino24_t<6>(p, st) : launch_wino24_t<3>(p, st);
 }
+hipError_t launch_wino24_c48(const WinoParams& p, hipStream_t st) { return launch_wino24_t<2, true>(p, st); }
 
 }  // namespace se

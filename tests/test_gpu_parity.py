@@ -152,6 +152,25 @@ def test_op_winograd_f43_path_vs_oracle(eng, case, monkeypatch):
     assert _md(y8, ref8) < TOL_OP * max(1.0, float(ref8.abs().max()))
 
 
+@pytest.mark.parametrize("size", [(16, 16), (6, 12), (64, 64), (10, 20)], ids=lambda s: "%dx%d" % s)
+def test_op_winograd_f43_48_channel_source_vs_oracle(eng, size, monkeypatch):
+    """xconv5 of netG (48 -> 192, 3x3, stride 1): the hybrid kernel's 48-channel instantiation (two chunks per position, the
+    second half empty: k-half 0 only) against the oracle and against the direct kernel (SE_WINOGRAD_F43=0)."""
+    from oracle import sketchedit_oracle as O
+    H, W = size
+    a = 1.5 / np.sqrt(48 * 9)
+    w = synth.uniform(19, "w24c48.w", (192, 48, 3, 3), -a, a)
+    b = synth.uniform(19, "w24c48.b", (192,), -0.3, 0.3)
+    x = synth.uniform(19, "w24c48.x%s" % (size,), (3, 48, H, W), -1, 1)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu")
+    monkeypatch.setenv("SE_WINOGRAD_F43", "1")
+    y = eng.gated_conv2d(_cuda(x), w, b)
+    monkeypatch.setenv("SE_WINOGRAD_F43", "0")
+    yd = eng.gated_conv2d(_cuda(x), w, b)
+    assert _md(y, ref) < TOL_OP and _md(yd, ref) < TOL_OP
+    assert _md(y, yd) < 2e-5 and _md(y, yd) > 0.0          # (two different kernels ran)
+
+
 WINO48 = [(1, 16, 16, "elu"), (1, 64, 64, "elu"), (2, 16, 24, "relu"), (4, 32, 16, "elu"), (1, 10, 14, "elu"),
           (1, 34, 30, "elu")]
 

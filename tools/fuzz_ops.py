@@ -34,7 +34,9 @@ def run(n, seed, verbose=True):
         ll = bool(rng.randint(0, 2))
         B = int(rng.randint(1, 4))
         H, W = int(rng.randint(4, 72)), int(rng.randint(4, 72))
-        rate = int(rng.choice([1, 1, 2, 4, 8])) if (cin, cout) == (96, 192) else 1
+        rate = int(rng.choice([1, 1, 2, 4, 8, 16, 3])) if (cin, cout) == (96, 192) else 1
+        if (cin, cout) == (96, 192) and rng.randint(0, 2):      # half of these cases on the hybrid Winograd kernel's grid (h % 2d == w % 4d == 0)
+            H, W = 2 * rate * int(rng.randint(1, max(2, 72 // (2 * rate)))), 4 * rate * int(rng.randint(1, max(2, 72 // (4 * rate))))
         act = "relu" if (rng.randint(0, 5) == 0 and not up) else "elu"
         a = 1.5 / np.sqrt(cin * ks * ks)
         tag = "fz%d.%d" % (seed, k)
