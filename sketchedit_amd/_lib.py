@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKETCHEDIT_HIP_LIB points at another build of the same library (developer builds, e.g. tools/wino_trace.py)
 LIB_PATH = os.environ.get("SKETCHEDIT_HIP_LIB") or os.path.join(_HERE, "lib", "libsketchedit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["se_gconv.hip", "se_rconv16.hip", "se_rconv96.hip", "se_rtile.hip", "se_wino.hip", "se_wino24.hip", "se_wino48.hip", "se_wino_up.hip", "se_wino_up48.hip", "se_attention.hip", "se_misc.hip",
+SOURCES = ["se_gconv.hip", "se_rconv16.hip", "se_rconv96.hip", "se_rtile.hip", "se_rtilew.hip", "se_wino.hip", "se_wino24.hip", "se_wino48.hip", "se_wino_up.hip", "se_wino_up48.hip", "se_attention.hip", "se_misc.hip",
            "se_api.hip"]
 
 SE_NET_G, SE_NET_M = 0, 1

@@ -84,6 +84,7 @@ struct Layer {
   float* d_u24 = nullptr;     // 96 -> 192 3x3: image of the hybrid F(2,3) x F(4,3) kernel (first 96 input channels), se_wino24.hip
   float* d_ub24 = nullptr;    //   and the bias in its MIXED row order
   float* d_u24b = nullptr;    //   two-source layers: the image over both sources (6 chunks per position)
+  float* d_wx = nullptr;      // 24 -> 24 3x3: image of the F(2,3)-along-x raw-tile kernel (se_rtilew.hip)
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
@@ -197,6 +198,7 @@ float bf16_round(float f);
 bool wino_eligible_layer(const LayerDef& d);
 int pack_wino(se_ctx* c, Layer& L);
 int pack_wino24(se_ctx* c, Layer& L);
+int pack_rtilew(se_ctx* c, Layer& L);
 bool wino48_eligible_layer(const LayerDef& d);
 int pack_wino48(se_ctx* c, Layer& L);
 bool winoup_eligible_layer(const LayerDef& d);
@@ -286,6 +288,7 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   L.packed = true;
   if (wino_eligible_layer(d) && Cp == d.cin) return pack_wino(c, L);
   if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 48 && d.cout == 192 && d.act != ACT_NONE && Cp == d.cin) return pack_wino24(c, L);      // xconv5
+  if (d.k == 3 && d.stride == 1 && !d.up && d.rate == 1 && d.cin == 24 && d.cout == 24 && d.act != ACT_NONE && Cp == d.cin) return pack_rtilew(c, L);   // conv16
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
   if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
   if (winoup48_eligible_layer(d) && Cp == d.cin) return pack_winoup48(c, L);
@@ -513,6 +516,33 @@ int pack_wino(se_ctx* c, Layer& L) {
     HIPCHK(c, hipMemcpy(L.d_wv16, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
   }
   return pack_wino24(c, L);
+}
+
+// 24 -> 24 layers (se_rtilew.hip): U[nu][ky] = G g[ky][.] with the F(2,3) G along x; k = ky * 24 + channel in three 32-k
+// chunks per position (72 k, the third chunk half empty), 24 PHYSICAL rows -- tile 0 = features 0-7, gates 0-7; then
+// features 8-11, gates 8-11 (the padding rows of the second MIXED tile read these again) --, slot swizzle by physical row.
+int pack_rtilew(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int G = d.cout / 2;      // 12
+  std::vector<float> img((size_t)4 * 3 * 24 * 32, 0.f);
+  for (int prow = 0; prow < 24; ++prow) {
+    const int oc = prow < 8 ? prow : prow < 16 ? G + (prow - 8) : prow < 20 ? 8 + (prow - 16) : G + 8 + (prow - 20);
+    for (int ic = 0; ic < 24; ++ic)
+      for (int ky = 0; ky < 3; ++ky) {
+        const float* g = &L.w[(((size_t)oc * d.cin + ic) * 3 + ky) * 3];
+        for (int nu = 0; nu < 4; ++nu) {
+          const float u = Gm[nu][0] * g[0] + Gm[nu][1] * g[1] + Gm[nu][2] * g[2];
+          const int k = ky * 24 + ic, ch = k / 32, kin = k % 32, s_ = kin / 4, e = kin % 4;
+          const int ps = s_ ^ ((prow >> 1) & 7);
+          img[(((size_t)nu * 3 + ch) * 24 + prow) * 32 + ps * 4 + e] = u;
+        }
+      }
+  }
+  if (L.d_wx) (void)hipFree(L.d_wx);
+  HIPCHK(c, hipMalloc(&L.d_wx, img.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_wx, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  return 0;
 }
 
 // Hybrid F(2,3) x F(4,3) image of the same layers (se_wino24.hip): U = Gy g Gx^T (4 x 6 positions) of the FIRST 96 input
@@ -800,6 +830,25 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   const int CG = bf ? L.CGp16 : L.CGp, nch = bf ? L.nch16 : L.nch;
   const float* wimg = bf ? L.d_w16 : L.d_w;
   if (!wimg || C0 != CG * gran) return 0;
+  // 24 -> 24 3x3: F(2,3) along x on the raw tile (se_rtilew.hip): 160 instead of 224 MFMAs per wave.  SE_RTILE_WX=0: the direct form
+  {
+    const char* wx_env = getenv("SE_RTILE_WX");       // (read per call: the tests compare both forms in one process)
+    if (!(wx_env && atoi(wx_env) == 0) && !bf && L.d_wx && d.k == 3 && !d.up && C0 == 24 && d.cin == 24 && d.cout == 24 && (Win % 2) == 0 &&
+        (long long)B * Hin * Win * 96 < (1ll << 31)) {
+      RTileParams p;
+      memset(&p, 0, sizeof p);
+      p.src = src0; p.wpk = L.d_wx; p.bias = L.d_b; p.dst = dst;
+      p.B = B; p.Hin = Hin; p.Win = Win; p.C = C0; p.G = L.G; p.OH = Ho; p.OW = Wo;
+      p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
+      p.act = d.act; p.xcd = xcd_remap_enabled(); p.NP = 32;
+      const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+      set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
+                      (double)B * p.ty * p.tx * 4.0 * 160.0 * 2048.0);       // 160 MFMAs of 16x16x4 per wave
+      HIPCHK(c, launch_rtilew(p, c->st));
+      *done = true;
+      return 0;
+    }
+  }
   // dense-K form of the 5x5 first layers (fp32): SE_RTILE_DENSE=0 keeps the channel-padded K
   static const bool dense_on = !(getenv("SE_RTILE_DENSE") && atoi(getenv("SE_RTILE_DENSE")) == 0);
   if (dense_on && !bf && L.d_wd && L.dense && d.k == 5 && !d.up && L.cfg == GC_N48 && (long long)Hin * Win * C0 * 4 < (1ll << 31)) {
@@ -1593,6 +1642,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_u1) (void)hipFree(kv.second.d_u1);
       if (kv.second.d_wv) (void)hipFree(kv.second.d_wv);
       if (kv.second.d_wv16) (void)hipFree(kv.second.d_wv16);
+      if (kv.second.d_wx) (void)hipFree(kv.second.d_wx);
       if (kv.second.d_u24) (void)hipFree(kv.second.d_u24);
       if (kv.second.d_ub24) (void)hipFree(kv.second.d_ub24);
       if (kv.second.d_u24b) (void)hipFree(kv.second.d_u24b);
@@ -1970,6 +2020,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_u1) (void)hipFree(L.d_u1);
   if (L.d_wv) (void)hipFree(L.d_wv);
   if (L.d_wv16) (void)hipFree(L.d_wv16);
+  if (L.d_wx) (void)hipFree(L.d_wx);
   if (L.d_u24) (void)hipFree(L.d_u24);
   if (L.d_ub24) (void)hipFree(L.d_ub24);
   if (L.d_u24b) (void)hipFree(L.d_u24b);

@@ -1,0 +1,185 @@
+// 24 -> 24 gated 3x3 convolution, stride 1 (conv16 / allconv16 / conv_mask_16 of /root/reference/models/networks/
+// editline_g.py:90-91,98-99 and editline2_g.py:32-33,40-41: the full-resolution layer in front of every 12 -> 3 / 12 -> 1
+// output conv; the layer itself is gen_conv, /root/reference/models/networks/utils.py:21-33) in raw-tile form with a
+// ONE-DIMENSIONAL Winograd transform: F(2,3) along x, the direct form along y.  Round 4.
+//
+//   out[y][2t + o] = sum_ky sum_c  A^T[o][nu] ( U[nu][ky][c] * V[y + ky - 1][t][nu][c] )
+//   V[r][t][.] = B^T (x[r][2t - 1 .. 2t + 2])       B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+//   U[nu][ky]  = G g[ky][.]                         G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]     A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// 12 (position, kernel row) taps per 2 outputs instead of 18: 1.5x fewer multiply-adds, all coefficients 0, +-1, +-1/2.
+// Why only along x: these layers run on 32 packed rows (24 real: the 25 % row padding no 16-row MFMA tiling avoids,
+// DESIGN.md 7b) with K = 24 per tap, so a two-dimensional transform wants its 16 (F(2x2,3x3)) or 24 transformed weight
+// planes resident next to the tiles -- 49 / 74 KB, which leaves no room for two workgroups per CU -- while the 12 taps of
+// this form are 36.9 KB.  The transformed tile of a source row serves the three output rows that read it, exactly as a
+// raw pixel does in rtile_kernel ("a tap is an address offset"), so the k loop is rtile_kernel's: no staging, no wait,
+// no barrier.
+//   * workgroup = 4 waves = 8 x 16 outputs; wave w = output rows 2w, 2w+1 x 8 x-tiles = 16 MFMA columns, both row tiles;
+//   * prologue: the whole weight image by LDS-DMA; every thread gathers the four source pixels of (row, x-tile, granule)
+//     tasks through the buffer range check (zero padding), transforms and writes T[row][nu][x-tile][24 channels] --
+//     480 tasks of 4 gathers, 4 packed adds, 4 LDS writes for 256 threads;
+//   * k loop per position nu: K = 3 kernel rows x 24 channels = 18 granules in three 32-k chunks, the third half empty
+//     (k-half 0 only, two of its four granules are padding with zero weights): 20 k-steps for 18 of work;
+//     160 MFMAs per wave instead of rtile_kernel's 224;
+//   * T entries are 96 bytes like rtile_kernel's pixels and a source row is 3072 bytes = 0 mod 256, so the 16 lanes of a
+//     fragment read (two rows x eight x-tiles) hit the banks exactly as 16 consecutive pixels do there: conflict-free;
+//   * the padding rows of the second row tile (rows 4-7 and 12-15 of [f8-11, -, g8-11, -]) read the LDS rows of the real
+//     ones, so the weight image holds 24 rows, not 32.
+#include "se_device.h"
+
+#include <type_traits>
+
+namespace se {
+
+__global__ __launch_bounds__(256, 2) void rtilew_kernel(const RTileParams p) {
+  constexpr int NT = 2, TR = 8, RH = TR + 2, NXT = 8;
+  constexpr int ENT = 96;                        // bytes of one T entry: 24 channels
+  constexpr int TNU = NXT * ENT;                 // 768: the eight x-tiles of one (row, nu)
+  constexpr int TROW = 4 * TNU;                  // 3072: one source row
+  constexpr int TB = RH * TROW;                  // 30720
+  constexpr int WCH = 24 * 128;                  // one 32-k chunk of the weight image (24 physical rows)
+  constexpr int WNU = 3 * WCH;                   // one position: 72 k in three chunks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* T = smem;
+  char* Wres = smem + TB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
+  const int ty0 = (t2 / p.tx) * TR, tx0 = (t2 % p.tx) * 16;
+
+  // ---- prologue: weights by LDS-DMA, then the transformed tile
+  {
+    const unsigned lds_w = lds_addr_of(Wres);
+    for (int i = w; i < 4 * WNU / 1024; i += 4) glds16_s(p.wpk + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * 96u), 0x00020000);
+    float negone = -1.f;
+    asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (se_wino.hip)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int k = tid + rep * 256;             // task = (source row, x-tile, granule)
+      if (k < RH * NXT * 6) {
+        const int row = k / 48, rem = k - row * 48, xt = rem / 6, g = rem - xt * 6;
+        const int sy = ty0 - 1 + row, sx0 = tx0 + 2 * xt - 1;
+        const bool yok = (unsigned)sy < (unsigned)p.Hin;
+        const unsigned rowoff = (unsigned)((b * p.Hin + sy) * p.Win) * 96u + (unsigned)g * 16u;
+        f32x4 d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sx = sx0 + j;
+          const unsigned off = (yok && (unsigned)sx < (unsigned)p.Win) ? rowoff + (unsigned)sx * 96u : 0x80000000u;
+          d[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+        }
+        char* at = T + row * TROW + xt * ENT + g * 16;
+        *(f32x4*)(at) = d[2] * negone + d[0];
+        *(f32x4*)(at + TNU) = d[1] + d[2];
+        *(f32x4*)(at + 2 * TNU) = d[1] * negone + d[2];
+        *(f32x4*)(at + 3 * TNU) = d[3] * negone + d[1];
+      }
+    }
+  }
+  const int jx = lane & 15, g4 = lane >> 4;
+  const int rl = jx >> 3, xt = jx & 7;
+  const int tbase = (2 * w + rl) * TROW + xt * ENT;
+  // raw-tile offset of granule gi = c * 4 + g4 of the flattened (kernel row, channel group) axis, c = (chunk, k-half)
+  int xoff[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const int gi = min(c * 4 + g4, 17);          // granules 18, 19: K padding -- zero weights, any valid address
+    const int ky = gi / 6, cg = gi - ky * 6;
+    xoff[c] = tbase + ky * TROW + cg * 16;
+  }
+  // A fragments: physical weight row of this lane's packed row in either row tile, with the usual slot swizzle
+  int aoff[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int prow = nt == 0 ? jx : 16 + ((jx >> 3) << 2) + (jx & 3);
+    aoff[nt][0] = prow * 128 + ((g4 ^ ((prow >> 1) & 7)) << 4);
+    aoff[nt][1] = prow * 128 + (((4 + g4) ^ ((prow >> 1) & 7)) << 4);
+  }
+  f32x4 oy[2][NT];                               // outputs x0, x1 of this lane's (row, x-tile): start at the bias
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) oy[0][nt] = oy[1][nt] = *(const f32x4*)(p.bias + nt * 16 + g4 * 4);
+
+  dma_wait_all();
+  __syncthreads();
+
+  float neg1 = -1.f;
+  asm volatile("" : "+v"(neg1));
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) {
+    f32x4 am[NT];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const int nh = ch < 2 ? 2 : 1;             // the third chunk carries k-half 0 only
+      f32x4 wq[2][NT], xb[2];
+#pragma unroll
+      for (int half = 0; half < nh; ++half) {
+        xb[half] = *(const f32x4*)(T + xoff[ch * 2 + half] + nu * TNU);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[half][nt] = *(const f32x4*)(Wres + nu * WNU + ch * WCH + aoff[nt][half]);
+      }
+#pragma unroll
+      for (int half = 0; half < nh; ++half)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 cin = (ch == 0 && half == 0 && r == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : am[nt];
+            am[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[half][nt][r], xb[half][r], cin, 0, 0, 0);
+          }
+    }
+    // A^T = [1 1 1 0; 0 1 -1 -1]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nu < 3) oy[0][nt] += am[nt];
+      if (nu == 1) oy[1][nt] += am[nt];
+      if (nu >= 2) oy[1][nt] = am[nt] * neg1 + oy[1][nt];
+    }
+  }
+
+  // ---- epilogue (rtile_kernel, MIXED): tile rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32)
+  const int q = lane >> 4;
+  const int lanec = (q & 1) * 4 + (q >> 1) * 2;                      // this lane's channel pair inside a row tile
+  const int y = ty0 + 2 * w + rl;
+  const bool oky = y < p.Hin;
+  auto epilogue = [&](auto elu_tag) {
+    constexpr bool ELU = decltype(elu_tag)::value;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool okc = oky && nt * 8 + lanec < p.G;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const f32x4 v = oy[o][nt];                                      // (bias already inside)
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+        const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+        const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+        float2 ov;
+        ov.x = (ELU ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
+        ov.y = (ELU ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+        const int x = tx0 + 2 * xt + o;
+        if (okc && x < p.Win)
+          *(float2*)(p.dst + ((size_t)(b * p.Hin + y) * p.Win + x) * p.G + nt * 8 + lanec) = ov;
+      }
+    }
+  };
+  if (p.act == 0) epilogue(std::true_type()); else epilogue(std::false_type());
+}
+
+hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
+  constexpr int LDS = 10 * 3072 + 4 * 3 * 24 * 128;      // transformed tile 30 KB + weights 36 KB
+  {
+    hipError_t e = ensure_max_lds((const void*)rtilew_kernel, 80 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  const int grid = p.B * p.ty * p.tx;
+  set_launch_grid(grid);
+  ProfScope ps_(st, PL_GCONV_N24);
+  hipLaunchKernelGGL(rtilew_kernel, dim3(grid), dim3(256), LDS, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace se
