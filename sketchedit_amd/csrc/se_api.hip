@@ -839,11 +839,13 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
       memset(&p, 0, sizeof p);
       p.src = src0; p.wpk = L.d_wx; p.bias = L.d_b; p.dst = dst;
       p.B = B; p.Hin = Hin; p.Win = Win; p.C = C0; p.G = L.G; p.OH = Ho; p.OW = Wo;
-      p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
+      p.ty = (Hin + 15) / 16; p.tx = (Win + 15) / 16;       // blocks of 16 x 16 outputs
       p.act = d.act; p.xcd = xcd_remap_enabled(); p.NP = 32;
+      udiv_magic_host((unsigned)(p.ty * p.tx), &p.div_cg_m, &p.div_cg_l);      // (reused fields: blk / (ty * tx), t2 / tx)
+      udiv_magic_host((unsigned)p.tx, &p.div_rw_m, &p.div_rw_l);
       const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
       set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
-                      (double)B * p.ty * p.tx * 4.0 * 160.0 * 2048.0);       // 160 MFMAs of 16x16x4 per wave
+                      (double)B * p.ty * p.tx * 8.0 * 160.0 * 2048.0);       // 160 MFMAs of 16x16x4 per wave and block
       HIPCHK(c, launch_rtilew(p, c->st));
       *done = true;
       return 0;

@@ -195,7 +195,7 @@ struct RTileParams {
 };
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st);
 // 24 -> 24 3x3 stride 1 with F(2,3) along x (se_rtilew.hip): src NHWC 24, wpk = image of pack_rtilew ([4 positions][3 chunks]
-// [24 physical rows][32 k]), bias [32] in the MIXED packed-row order, dst NHWC 12; Win even; ty = ceil(H / 8), tx = ceil(W / 16)
+// [24 physical rows][32 k]), bias [32] in the MIXED packed-row order, dst NHWC 12; Win even; ty = ceil(H / 16), tx = ceil(W / 16): blocks of 16 x 16 outputs, walked by persistent workgroups
 hipError_t launch_rtilew(const RTileParams& p, hipStream_t st);
 int rtile_rows(bool bf16);    // output rows per workgroup tile (8 fp32, 32 bf16)
 

@@ -14,10 +14,14 @@
 // this form are 36.9 KB.  The transformed tile of a source row serves the three output rows that read it, exactly as a
 // raw pixel does in rtile_kernel ("a tap is an address offset"), so the k loop is rtile_kernel's: no staging, no wait,
 // no barrier.
-//   * workgroup = 4 waves = 8 x 16 outputs; wave w = output rows 2w, 2w+1 x 8 x-tiles = 16 MFMA columns, both row tiles;
-//   * prologue: the whole weight image by LDS-DMA; every thread gathers the four source pixels of (row, x-tile, granule)
-//     tasks through the buffer range check (zero padding), transforms and writes T[row][nu][x-tile][24 channels] --
-//     480 tasks of 4 gathers, 4 packed adds, 4 LDS writes for 256 threads;
+//   * PERSISTENT workgroups, one per CU (8 waves, 147 KB of LDS): the weight image is loaded once, a workgroup walks
+//     blocks of 16 x 16 outputs; wave w = output rows 2w, 2w+1 x 8 x-tiles = 16 MFMA columns, both row tiles;
+//   * every thread gathers the four source pixels of (row, x-tile, granule) tasks through the buffer range check (zero
+//     padding), transforms and writes T[row][nu][x-tile][24 channels] -- 864 tasks of 4 gathers, 4 packed adds, 4 LDS
+//     writes for 512 threads -- for block i+1 while block i runs: the gathers are issued in front of the k loop and
+//     consumed behind the epilogue (two T buffers, one barrier per block).  The first form -- one 8 x 16 block per
+//     workgroup, two workgroups per CU, synchronous prologue -- measured 258 us per launch against rtile_kernel's 271:
+//     its gather round trip was exposed once per 5120 cycles of MFMAs;
 //   * k loop per position nu: K = 3 kernel rows x 24 channels = 18 granules in three 32-k chunks, the third half empty
 //     (k-half 0 only, two of its four granules are padding with zero weights): 20 k-steps for 18 of work;
 //     160 MFMAs per wave instead of rtile_kernel's 224;
@@ -31,55 +35,77 @@
 
 namespace se {
 
-__global__ __launch_bounds__(256, 2) void rtilew_kernel(const RTileParams p) {
-  constexpr int NT = 2, TR = 8, RH = TR + 2, NXT = 8;
+__global__ __launch_bounds__(512, 2) void rtilew_kernel(const RTileParams p) {
+  constexpr int NT = 2, TR = 16, RH = TR + 2, NXT = 8;
   constexpr int ENT = 96;                        // bytes of one T entry: 24 channels
   constexpr int TNU = NXT * ENT;                 // 768: the eight x-tiles of one (row, nu)
   constexpr int TROW = 4 * TNU;                  // 3072: one source row
-  constexpr int TB = RH * TROW;                  // 30720
+  constexpr int TB = RH * TROW;                  // 55296
   constexpr int WCH = 24 * 128;                  // one 32-k chunk of the weight image (24 physical rows)
   constexpr int WNU = 3 * WCH;                   // one position: 72 k in three chunks
+  constexpr int NTASK = RH * NXT * 6;            // 864 (source row, x-tile, granule) transform tasks per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* T = smem;
-  char* Wres = smem + TB;
+  char* Wres = smem + 2 * TB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
-  const int ty0 = (t2 / p.tx) * TR, tx0 = (t2 % p.tx) * 16;
-
-  // ---- prologue: weights by LDS-DMA, then the transformed tile
-  {
-    const unsigned lds_w = lds_addr_of(Wres);
-    for (int i = w; i < 4 * WNU / 1024; i += 4) glds16_s(p.wpk + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * 96u), 0x00020000);
-    float negone = -1.f;
-    asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (se_wino.hip)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int nblk = p.B * p.ty * p.tx;
+  auto block_origin = [&](int blk, int& b, int& ty0, int& tx0) {      // (wave-uniform: scalar arithmetic)
+    b = (int)udiv_magic((unsigned)blk, p.div_cg_m, p.div_cg_l);        // blk / (ty * tx)
+    const int t2 = blk - b * (p.ty * p.tx);
+    const int by = (int)udiv_magic((unsigned)t2, p.div_rw_m, p.div_rw_l);   // t2 / tx
+    ty0 = by * TR;
+    tx0 = (t2 - by * p.tx) * 16;
+  };
+  // transform tasks of this thread: k = tid, tid + 512 (the second only for tid < 352)
+  int trow[2], txt[2], tg[2];
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int k = min(tid + rep * 512, NTASK - 1);
+    trow[rep] = k / 48;
+    const int rem = k - trow[rep] * 48;
+    txt[rep] = rem / 6;
+    tg[rep] = rem - txt[rep] * 6;
+  }
+  const bool task1 = tid + 512 < NTASK;
+  unsigned lane_src[2];
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) lane_src[rep] = (unsigned)(trow[rep] * p.Win) * 96u + (unsigned)tg[rep] * 16u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * 96u), 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // the four source pixels of every task of block `blk`, through the buffer range check (outside the image: zeros)
+  auto gather = [&](int blk, f32x4 (&d)[2][4]) {
+    int b, ty0, tx0;
+    block_origin(blk, b, ty0, tx0);
+    const unsigned srow0 = (unsigned)((b * p.Hin + ty0 - 1) * p.Win) * 96u;      // source row ty0 - 1, column 0 (scalar)
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
-      const int k = tid + rep * 256;             // task = (source row, x-tile, granule)
-      if (k < RH * NXT * 6) {
-        const int row = k / 48, rem = k - row * 48, xt = rem / 6, g = rem - xt * 6;
-        const int sy = ty0 - 1 + row, sx0 = tx0 + 2 * xt - 1;
-        const bool yok = (unsigned)sy < (unsigned)p.Hin;
-        const unsigned rowoff = (unsigned)((b * p.Hin + sy) * p.Win) * 96u + (unsigned)g * 16u;
-        f32x4 d[4];
+      // row part + column part, either 0x80000000 when outside the image: their SATURATING sum is out of the buffer's range
+      // then and the gather returns zeros (se_wino.hip).  Both parts are non-negative when valid (row offset of column 0, column
+      // offset inside the row); lane_src[rep] = row * Win * 96 + 16 g and the x-tile's first column are block-invariant.
+      const int sy = ty0 - 1 + trow[rep], sx0 = tx0 + 2 * txt[rep] - 1;
+      const unsigned yo = ((unsigned)sy < (unsigned)p.Hin && (rep == 0 || task1)) ? srow0 + lane_src[rep] : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int sx = sx0 + j;
-          const unsigned off = (yok && (unsigned)sx < (unsigned)p.Win) ? rowoff + (unsigned)sx * 96u : 0x80000000u;
-          d[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
-        }
-        char* at = T + row * TROW + xt * ENT + g * 16;
-        *(f32x4*)(at) = d[2] * negone + d[0];
-        *(f32x4*)(at + TNU) = d[1] + d[2];
-        *(f32x4*)(at + 2 * TNU) = d[1] * negone + d[2];
-        *(f32x4*)(at + 3 * TNU) = d[3] * negone + d[1];
+      for (int j = 0; j < 4; ++j) {
+        const unsigned xo = (unsigned)(sx0 + j) < (unsigned)p.Win ? (unsigned)(sx0 + j) * 96u : 0x80000000u;
+        d[rep][j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)__builtin_elementwise_add_sat(yo, xo), 0, 0));
       }
     }
-  }
+  };
+  float negone = -1.f;
+  asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (se_wino.hip)
+  auto transform = [&](char* T, const f32x4 (&d)[2][4]) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      if (rep == 1 && !task1) break;
+      char* at = T + trow[rep] * TROW + txt[rep] * ENT + tg[rep] * 16;
+      *(f32x4*)(at) = d[rep][2] * negone + d[rep][0];
+      *(f32x4*)(at + TNU) = d[rep][1] + d[rep][2];
+      *(f32x4*)(at + 2 * TNU) = d[rep][1] * negone + d[rep][2];
+      *(f32x4*)(at + 3 * TNU) = d[rep][3] * negone + d[rep][1];
+    }
+  };
+
   const int jx = lane & 15, g4 = lane >> 4;
   const int rl = jx >> 3, xt = jx & 7;
   const int tbase = (2 * w + rl) * TROW + xt * ENT;
@@ -99,86 +125,119 @@ __global__ __launch_bounds__(256, 2) void rtilew_kernel(const RTileParams p) {
     aoff[nt][0] = prow * 128 + ((g4 ^ ((prow >> 1) & 7)) << 4);
     aoff[nt][1] = prow * 128 + (((4 + g4) ^ ((prow >> 1) & 7)) << 4);
   }
-  f32x4 oy[2][NT];                               // outputs x0, x1 of this lane's (row, x-tile): start at the bias
+  f32x4 bias4[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) oy[0][nt] = oy[1][nt] = *(const f32x4*)(p.bias + nt * 16 + g4 * 4);
+  for (int nt = 0; nt < NT; ++nt) bias4[nt] = *(const f32x4*)(p.bias + nt * 16 + g4 * 4);
+  float neg1 = -1.f;
+  asm volatile("" : "+v"(neg1));
+  const int q = lane >> 4;
+  const int lanec = (q & 1) * 4 + (q >> 1) * 2;                      // this lane's channel pair inside a row tile
+  const unsigned lane_dst = (unsigned)(((2 * w + rl) * p.Win + 2 * xt) * p.G + lanec) * 4u;      // byte offset inside a block
 
+  // ---- prologue: the weights once per workgroup (LDS-DMA), the first block's transformed tile
+  {
+    const unsigned lds_w = lds_addr_of(Wres);
+    for (int i = w; i < 4 * WNU / 1024; i += 8) glds16_s(p.wpk + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
+  }
+  f32x4 d[2][4];
+  int blk = blockIdx.x;
+  if (blk < nblk) {
+    gather(blk, d);
+    transform(smem, d);
+  }
   dma_wait_all();
   __syncthreads();
 
-  float neg1 = -1.f;
-  asm volatile("" : "+v"(neg1));
+  // ---- persistent loop over this workgroup's blocks: the gathers of block i+1 fly under the MFMAs of block i
+  for (int it = 0; blk < nblk; blk += gridDim.x, ++it) {
+    const int nxt = blk + gridDim.x;
+    if (nxt < nblk) gather(nxt, d);
+    int b, ty0, tx0;
+    block_origin(blk, b, ty0, tx0);
+    const char* T = smem + (it & 1) * TB;
+    f32x4 oy[2][NT];                             // outputs x0, x1 of this lane's (row, x-tile): start at the bias
 #pragma unroll
-  for (int nu = 0; nu < 4; ++nu) {
-    f32x4 am[NT];
+    for (int nt = 0; nt < NT; ++nt) oy[0][nt] = oy[1][nt] = bias4[nt];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const int nh = ch < 2 ? 2 : 1;             // the third chunk carries k-half 0 only
-      f32x4 wq[2][NT], xb[2];
+    for (int nu = 0; nu < 4; ++nu) {
+      f32x4 am[NT];
 #pragma unroll
-      for (int half = 0; half < nh; ++half) {
-        xb[half] = *(const f32x4*)(T + xoff[ch * 2 + half] + nu * TNU);
+      for (int ch = 0; ch < 3; ++ch) {
+        const int nh = ch < 2 ? 2 : 1;           // the third chunk carries k-half 0 only
+        f32x4 wq[2][NT], xb[2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wq[half][nt] = *(const f32x4*)(Wres + nu * WNU + ch * WCH + aoff[nt][half]);
+        for (int half = 0; half < nh; ++half) {
+          xb[half] = *(const f32x4*)(T + xoff[ch * 2 + half] + nu * TNU);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) wq[half][nt] = *(const f32x4*)(Wres + nu * WNU + ch * WCH + aoff[nt][half]);
+        }
+#pragma unroll
+        for (int half = 0; half < nh; ++half)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const f32x4 cin = (ch == 0 && half == 0 && r == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : am[nt];
+              am[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[half][nt][r], xb[half][r], cin, 0, 0, 0);
+            }
       }
+      // A^T = [1 1 1 0; 0 1 -1 -1]
 #pragma unroll
-      for (int half = 0; half < nh; ++half)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 cin = (ch == 0 && half == 0 && r == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : am[nt];
-            am[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[half][nt][r], xb[half][r], cin, 0, 0, 0);
-          }
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nu < 3) oy[0][nt] += am[nt];
+        if (nu == 1) oy[1][nt] += am[nt];
+        if (nu >= 2) oy[1][nt] = am[nt] * neg1 + oy[1][nt];
+      }
     }
-    // A^T = [1 1 1 0; 0 1 -1 -1]
+    // epilogue (rtile_kernel, MIXED): tile rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32).  Store address =
+    // one scalar block base + a block-invariant 32-bit lane offset + compile-time increments (no 64-bit vector arithmetic)
+    const int y = ty0 + 2 * w + rl;
+    const bool oky = y < p.Hin;
+    char* dblk = (char*)p.dst + ((size_t)(b * p.Hin + ty0) * p.Win + tx0) * (size_t)(p.G * 4);
+    auto epilogue = [&](auto elu_tag) {
+      constexpr bool ELU = decltype(elu_tag)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (nu < 3) oy[0][nt] += am[nt];
-      if (nu == 1) oy[1][nt] += am[nt];
-      if (nu >= 2) oy[1][nt] = am[nt] * neg1 + oy[1][nt];
-    }
+      for (int nt = 0; nt < NT; ++nt) {
+        const bool okc = oky && nt * 8 + lanec < p.G;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const f32x4 v = oy[o][nt];                                    // (bias already inside)
+          const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+          const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+          const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+          float2 ov;
+          ov.x = (ELU ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
+          ov.y = (ELU ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+          const int x = tx0 + 2 * xt + o;
+          if (okc && x < p.Win)
+            *(float2*)(dblk + (lane_dst + (unsigned)(o * p.G * 4 + nt * 32))) = ov;
+        }
+      }
+    };
+    if (p.act == 0) epilogue(std::true_type()); else epilogue(std::false_type());
+    if (nxt < nblk) transform(smem + ((it + 1) & 1) * TB, d);
+    __syncthreads();
   }
-
-  // ---- epilogue (rtile_kernel, MIXED): tile rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32)
-  const int q = lane >> 4;
-  const int lanec = (q & 1) * 4 + (q >> 1) * 2;                      // this lane's channel pair inside a row tile
-  const int y = ty0 + 2 * w + rl;
-  const bool oky = y < p.Hin;
-  auto epilogue = [&](auto elu_tag) {
-    constexpr bool ELU = decltype(elu_tag)::value;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bool okc = oky && nt * 8 + lanec < p.G;
-#pragma unroll
-      for (int o = 0; o < 2; ++o) {
-        const f32x4 v = oy[o][nt];                                      // (bias already inside)
-        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
-        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
-        const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
-        const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
-        float2 ov;
-        ov.x = (ELU ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
-        ov.y = (ELU ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
-        const int x = tx0 + 2 * xt + o;
-        if (okc && x < p.Win)
-          *(float2*)(p.dst + ((size_t)(b * p.Hin + y) * p.Win + x) * p.G + nt * 8 + lanec) = ov;
-      }
-    }
-  };
-  if (p.act == 0) epilogue(std::true_type()); else epilogue(std::false_type());
 }
 
 hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
-  constexpr int LDS = 10 * 3072 + 4 * 3 * 24 * 128;      // transformed tile 30 KB + weights 36 KB
+  constexpr int LDS = 2 * 18 * 3072 + 4 * 3 * 24 * 128;      // two transformed tiles 108 KB + weights 36 KB
   {
-    hipError_t e = ensure_max_lds((const void*)rtilew_kernel, 80 * 1024);
+    hipError_t e = ensure_max_lds((const void*)rtilew_kernel, LDS);
     if (e != hipSuccess) return e;
   }
-  const int grid = p.B * p.ty * p.tx;
+  const int nblk = p.B * p.ty * p.tx;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  const int grid = nblk < cus ? nblk : cus;      // persistent: one workgroup per CU (147 KB of LDS), each walks nblk / grid blocks
   set_launch_grid(grid);
   ProfScope ps_(st, PL_GCONV_N24);
-  hipLaunchKernelGGL(rtilew_kernel, dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL(rtilew_kernel, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
 }
 
