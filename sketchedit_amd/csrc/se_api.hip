@@ -85,6 +85,7 @@ struct Layer {
   float* d_ub24 = nullptr;    //   and the bias in its MIXED row order
   float* d_u24b = nullptr;    //   two-source layers: the image over both sources (6 chunks per position)
   float* d_wx = nullptr;      // 24 -> 24 3x3: image of the F(2,3)-along-x raw-tile kernel (se_rtilew.hip)
+  float* d_wx2 = nullptr;     //   and of its two-dimensional F(2x2,3x3) form
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
@@ -542,6 +543,28 @@ int pack_rtilew(se_ctx* c, Layer& L) {
   if (L.d_wx) (void)hipFree(L.d_wx);
   HIPCHK(c, hipMalloc(&L.d_wx, img.size() * 4));
   HIPCHK(c, hipMemcpy(L.d_wx, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  // two-dimensional form: U = G g G^T per position; a row holds its 24 k as channels 0-15 in slots 0-3 and channels
+  // 16 + 2q, 17 + 2q in the first two elements of slot 4 + q (k-half 1 issues two k-steps)
+  std::vector<float> img2((size_t)16 * 24 * 32, 0.f);
+  for (int prow = 0; prow < 24; ++prow) {
+    const int oc = prow < 8 ? prow : prow < 16 ? G + (prow - 8) : prow < 20 ? 8 + (prow - 16) : G + 8 + (prow - 20);
+    for (int ic = 0; ic < 24; ++ic) {
+      const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
+      float t[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int kx = 0; kx < 3; ++kx) t[i][kx] = Gm[i][0] * g[kx] + Gm[i][1] * g[3 + kx] + Gm[i][2] * g[6 + kx];
+      for (int pos = 0; pos < 16; ++pos) {
+        const int xi = pos >> 2, nu = pos & 3;
+        const float u = t[xi][0] * Gm[nu][0] + t[xi][1] * Gm[nu][1] + t[xi][2] * Gm[nu][2];
+        const int s_ = ic < 16 ? ic / 4 : 4 + (ic - 16) / 2, e = ic < 16 ? ic % 4 : (ic - 16) % 2;
+        const int ps = s_ ^ ((prow >> 1) & 7);
+        img2[((size_t)pos * 24 + prow) * 32 + ps * 4 + e] = u;
+      }
+    }
+  }
+  if (L.d_wx2) (void)hipFree(L.d_wx2);
+  HIPCHK(c, hipMalloc(&L.d_wx2, img2.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_wx2, img2.data(), img2.size() * 4, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -844,8 +867,15 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
       udiv_magic_host((unsigned)(p.ty * p.tx), &p.div_cg_m, &p.div_cg_l);      // (reused fields: blk / (ty * tx), t2 / tx)
       udiv_magic_host((unsigned)p.tx, &p.div_rw_m, &p.div_rw_l);
       const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+      const bool two_d = !(wx_env && atoi(wx_env) == 1) && L.d_wx2 && (Hin % 2) == 0;       // SE_RTILE_WX=1: the one-dimensional form
       set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
-                      (double)B * p.ty * p.tx * 8.0 * 160.0 * 2048.0);       // 160 MFMAs of 16x16x4 per wave and block
+                      (double)B * p.ty * p.tx * 8.0 * (two_d ? 96.0 : 160.0) * 2048.0);       // MFMAs of 16x16x4 per wave and block
+      if (two_d) {
+        p.wpk = L.d_wx2;
+        HIPCHK(c, launch_rtilew2(p, c->st));
+        *done = true;
+        return 0;
+      }
       HIPCHK(c, launch_rtilew(p, c->st));
       *done = true;
       return 0;
@@ -1645,6 +1675,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_wv) (void)hipFree(kv.second.d_wv);
       if (kv.second.d_wv16) (void)hipFree(kv.second.d_wv16);
       if (kv.second.d_wx) (void)hipFree(kv.second.d_wx);
+      if (kv.second.d_wx2) (void)hipFree(kv.second.d_wx2);
       if (kv.second.d_u24) (void)hipFree(kv.second.d_u24);
       if (kv.second.d_ub24) (void)hipFree(kv.second.d_ub24);
       if (kv.second.d_u24b) (void)hipFree(kv.second.d_u24b);
@@ -2023,6 +2054,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_wv) (void)hipFree(L.d_wv);
   if (L.d_wv16) (void)hipFree(L.d_wv16);
   if (L.d_wx) (void)hipFree(L.d_wx);
+  if (L.d_wx2) (void)hipFree(L.d_wx2);
   if (L.d_u24) (void)hipFree(L.d_u24);
   if (L.d_ub24) (void)hipFree(L.d_ub24);
   if (L.d_u24b) (void)hipFree(L.d_u24b);

@@ -197,6 +197,9 @@ hipError_t launch_rtile(const RTileParams& p, hipStream_t st);
 // 24 -> 24 3x3 stride 1 with F(2,3) along x (se_rtilew.hip): src NHWC 24, wpk = image of pack_rtilew ([4 positions][3 chunks]
 // [24 physical rows][32 k]), bias [32] in the MIXED packed-row order, dst NHWC 12; Win even; ty = ceil(H / 16), tx = ceil(W / 16): blocks of 16 x 16 outputs, walked by persistent workgroups
 hipError_t launch_rtilew(const RTileParams& p, hipStream_t st);
+// the same layers with the two-dimensional F(2x2,3x3) transform (Hin and Win even): wpk = image of pack_rtilew2
+// ([16 positions][24 physical rows][32 floats]: channels 0-15 in slots 0-3, channels 16+2q, 17+2q in slot 4+q)
+hipError_t launch_rtilew2(const RTileParams& p, hipStream_t st);
 int rtile_rows(bool bf16);    // output rows per workgroup tile (8 fp32, 32 bf16)
 
 // ---------------------------------------------------------------------------------------------

@@ -221,6 +221,202 @@ __global__ __launch_bounds__(512, 2) void rtilew_kernel(const RTileParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layers with the full two-dimensional F(2x2,3x3) transform (even heights and widths; the default).  With
+// persistent workgroups the 16 transformed weight planes (24 physical rows x 128 B each = 48 KB) are loaded ONCE and the
+// rest of the CU's LDS holds the transformed tiles of one 16 x 16 block: T[16 positions][64 tiles][24 channels] = 96 KB --
+// what did not fit beside two workgroups per CU fits beside none.  96 MFMAs per wave and block instead of 160 (F(2,3)
+// along x) and 224 (direct).
+//   * a thread owns (tile, granule): 16 gathers of its 4 x 4 patch (issued under the MFMAs of the block before), the
+//     separable transform in registers (32 register operations), 16 LDS writes -- one task for 384 of the 512 threads;
+//   * wave w: row tile w & 1, column tile (16 tiles = two tile rows) w >> 1; a position is K = 24 = 6 k-steps: channels
+//     0-15 as four 16-byte granules (k-half 0), channels 16-23 as four 8-byte pieces of which k-steps 0, 1 take one
+//     element each -- no K padding; two positions run interleaved (two independent accumulators);
+//   * T has one buffer: [MFMA phase + epilogue] barrier [transform of the next block] barrier.
+// Measured (256 x 256, batch 32; same box): direct rtile_kernel 271 us, F(2,3) along x 207 us, this form 191 us per launch.
+// Its MFMAs are no longer what binds: removed one at a time (timing builds), the next block's gathers are 14 % of a launch,
+// the transform 13 %, the MFMAs + folds 10 %, the activation arithmetic 6 %; the rest is the serial chain of a block
+// (two barriers, 32 LDS writes, fragment reads, stores) that one workgroup per CU cannot overlap with anything.  Also
+// measured on the one-dimensional form, without effect: gathers two blocks ahead (two register sets), and two 4-wave
+// workgroups per CU with one T buffer each (201 instead of 207 us).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
+  constexpr int ENT = 96, NTILE = 64;
+  constexpr int TPOS = NTILE * ENT;              // 6144: the 64 tiles of one position
+  constexpr int TB = 16 * TPOS;                  // 98304
+  constexpr int WPOS = 24 * 128;                 // one position of the weight image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* T = smem;
+  char* Wres = smem + TB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = w & 1, ct = w >> 1;
+  const int nblk = p.B * p.ty * p.tx;
+  auto block_origin = [&](int blk, int& b, int& ty0, int& tx0) {      // (wave-uniform: scalar arithmetic)
+    b = (int)udiv_magic((unsigned)blk, p.div_cg_m, p.div_cg_l);        // blk / (ty * tx)
+    const int t2 = blk - b * (p.ty * p.tx);
+    const int by = (int)udiv_magic((unsigned)t2, p.div_rw_m, p.div_rw_l);   // t2 / tx
+    ty0 = by * 16;
+    tx0 = (t2 - by * p.tx) * 16;
+  };
+  // transform task of this thread: (tile, granule) for tid < 384
+  const bool has_task = tid < NTILE * 6;
+  const int tt = has_task ? tid / 6 : 0, tgr = has_task ? tid - tt * 6 : 0;
+  const int ttyl = tt >> 3, ttxl = tt & 7;
+  const unsigned rowbytes = (unsigned)p.Win * 96u;
+  const unsigned lane_y0 = (unsigned)(2 * ttyl) * rowbytes + (unsigned)tgr * 16u;       // patch row 0 relative to source row ty0 - 1
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.Hin * (unsigned)p.Win * 96u), 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto gather = [&](int blk, f32x4 (&d)[4][4]) {
+    int b, ty0, tx0;
+    block_origin(blk, b, ty0, tx0);
+    const unsigned srow0 = (unsigned)((b * p.Hin + ty0 - 1) * p.Win) * 96u;      // source row ty0 - 1, column 0 (scalar)
+    unsigned yo[4], xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sy = ty0 + 2 * ttyl - 1 + i, sx = tx0 + 2 * ttxl - 1 + i;
+      yo[i] = (has_task && (unsigned)sy < (unsigned)p.Hin) ? srow0 + lane_y0 + (unsigned)i * rowbytes : 0x80000000u;
+      xo[i] = (unsigned)sx < (unsigned)p.Win ? (unsigned)sx * 96u : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        d[i][j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)__builtin_elementwise_add_sat(yo[i], xo[j]), 0, 0));
+  };
+  float negone = -1.f;
+  asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (se_wino.hip)
+  // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: columns first (in place), then rows
+  auto transform = [&](f32x4 (&d)[4][4]) {
+    if (!has_task) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 c0 = d[i][2] * negone + d[i][0], c1 = d[i][1] + d[i][2], c2 = d[i][1] * negone + d[i][2], c3 = d[i][3] * negone + d[i][1];
+      d[i][0] = c0; d[i][1] = c1; d[i][2] = c2; d[i][3] = c3;
+    }
+    char* at = T + tt * ENT + tgr * 16;
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      *(f32x4*)(at + (0 * 4 + nu) * TPOS) = d[2][nu] * negone + d[0][nu];
+      *(f32x4*)(at + (1 * 4 + nu) * TPOS) = d[1][nu] + d[2][nu];
+      *(f32x4*)(at + (2 * 4 + nu) * TPOS) = d[1][nu] * negone + d[2][nu];
+      *(f32x4*)(at + (3 * 4 + nu) * TPOS) = d[3][nu] * negone + d[1][nu];
+    }
+  };
+
+  const int jx = lane & 15, g4 = lane >> 4;
+  // B fragments: this lane's tile of the wave's column tile; k-half 0 = granule g4, k-half 1 = the 8-byte piece g4 of channels 16-23
+  const int xoff0 = (ct * 16 + jx) * ENT + g4 * 16, xoff1 = (ct * 16 + jx) * ENT + 64 + g4 * 8;
+  // A fragments: physical weight row of this lane's packed row, with the usual slot swizzle
+  const int prow = rt == 0 ? jx : 16 + ((jx >> 3) << 2) + (jx & 3);
+  const int aoff0 = prow * 128 + ((g4 ^ ((prow >> 1) & 7)) << 4), aoff1 = prow * 128 + (((4 + g4) ^ ((prow >> 1) & 7)) << 4);
+  const f32x4 bias4 = *(const f32x4*)(p.bias + rt * 16 + g4 * 4);
+  float neg1 = -1.f;
+  asm volatile("" : "+v"(neg1));
+  const int lanec = (g4 & 1) * 4 + (g4 >> 1) * 2;                    // this lane's channel pair inside the row tile
+  const int tle = ct * 16 + jx, tyl = tle >> 3, txl = tle & 7;       // the tile whose outputs this lane holds
+  const unsigned lane_dst = (unsigned)((2 * tyl * p.Win + 2 * txl) * p.G + rt * 8 + lanec) * 4u;      // byte offset inside a block
+  const unsigned dinc_y = (unsigned)(p.Win * p.G) * 4u, dinc_x = (unsigned)p.G * 4u;
+
+  // ---- prologue: the weights once per workgroup (LDS-DMA), the first block's transformed tiles
+  {
+    const unsigned lds_w = lds_addr_of(Wres);
+    for (int i = w; i < 16 * WPOS / 1024; i += 8) glds16_s(p.wpk + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
+  }
+  f32x4 d[4][4];
+  int blk = blockIdx.x;
+  if (blk < nblk) {
+    gather(blk, d);
+    transform(d);
+  }
+  dma_wait_all();
+  __syncthreads();
+
+  for (; blk < nblk; blk += gridDim.x) {
+    const int nxt = blk + gridDim.x;
+    if (nxt < nblk) gather(nxt, d);              // flies under the MFMA phase
+    int b, ty0, tx0;
+    block_origin(blk, b, ty0, tx0);
+    f32x4 oy[2][2];                              // the 2 x 2 outputs of this lane's tile: start at the bias
+    oy[0][0] = oy[0][1] = oy[1][0] = oy[1][1] = bias4;
+    // ---- MFMA phase: 16 positions, two at a time (independent accumulators), each 4 + 2 k-steps; the fragments of the next
+    // pair are read in front of this pair's MFMAs (with one workgroup per CU nothing else hides the LDS latency)
+    f32x4 wa[2][2], xa[2][2];
+    f32x2 wb[2][2], xb[2][2];
+    auto read_pair = [&](int pp, int s_) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pos = 2 * pp + u;
+        wa[s_][u] = *(const f32x4*)(Wres + pos * WPOS + aoff0);
+        wb[s_][u] = *(const f32x2*)(Wres + pos * WPOS + aoff1);
+        xa[s_][u] = *(const f32x4*)(T + pos * TPOS + xoff0);
+        xb[s_][u] = *(const f32x2*)(T + pos * TPOS + xoff1);
+      }
+    };
+    read_pair(0, 0);
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      const int s_ = pp & 1;
+      if (pp + 1 < 8) read_pair(pp + 1, s_ ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 am[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          am[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_][u][r], xa[s_][u][r], r == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : am[u], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          am[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s_][u][r], xb[s_][u][r], am[u], 0, 0, 0);
+      // Y[a][bb] += At[a][xi] At[bb][nu] M,  At = [1 1 1 0; 0 1 -1 -1]
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pos = 2 * pp + u, xi = pos >> 2, nu = pos & 3;
+        const int ay[2] = {xi < 3 ? 1 : 0, xi == 0 ? 0 : (xi == 1 ? 1 : -1)};
+        const int ax[2] = {nu < 3 ? 1 : 0, nu == 0 ? 0 : (nu == 1 ? 1 : -1)};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const int c = ay[a] * ax[bb];
+            if (c > 0) oy[a][bb] += am[u];
+            else if (c < 0) oy[a][bb] = am[u] * neg1 + oy[a][bb];
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue (MIXED): rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32)
+    char* dblk = (char*)p.dst + ((size_t)(b * p.Hin + ty0) * p.Win + tx0) * (size_t)(p.G * 4);
+    const int y0 = ty0 + 2 * tyl, x0 = tx0 + 2 * txl;
+    const bool okc = rt * 8 + lanec < p.G;
+    auto epilogue = [&](auto elu_tag) {
+      constexpr bool ELU = decltype(elu_tag)::value;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const f32x4 v = oy[a][bb];                                    // (bias already inside)
+          const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+          const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+          const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+          float2 ov;
+          ov.x = (ELU ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
+          ov.y = (ELU ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
+          if (okc && y0 + a < p.Hin && x0 + bb < p.Win)
+            *(float2*)(dblk + (lane_dst + (unsigned)a * dinc_y + (unsigned)bb * dinc_x)) = ov;
+        }
+    };
+    if (p.act == 0) epilogue(std::true_type()); else epilogue(std::false_type());
+    __syncthreads();                             // every wave has read T
+    if (nxt < nblk) transform(d);
+    __syncthreads();
+  }
+}
+
 hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 18 * 3072 + 4 * 3 * 24 * 128;      // two transformed tiles 108 KB + weights 36 KB
   {
@@ -238,6 +434,26 @@ hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
   set_launch_grid(grid);
   ProfScope ps_(st, PL_GCONV_N24);
   hipLaunchKernelGGL(rtilew_kernel, dim3(grid), dim3(512), LDS, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_rtilew2(const RTileParams& p, hipStream_t st) {
+  constexpr int LDS = 16 * 64 * 96 + 16 * 24 * 128;      // transformed tiles 96 KB + weights 48 KB
+  {
+    hipError_t e = ensure_max_lds((const void*)rtilew2_kernel, LDS);
+    if (e != hipSuccess) return e;
+  }
+  const int nblk = p.B * p.ty * p.tx;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  const int grid = nblk < cus ? nblk : cus;
+  set_launch_grid(grid);
+  ProfScope ps_(st, PL_GCONV_N24);
+  hipLaunchKernelGGL(rtilew2_kernel, dim3(grid), dim3(512), LDS, st, p);
   return hipGetLastError();
 }
 

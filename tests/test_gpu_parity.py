@@ -171,14 +171,15 @@ def test_op_winograd_f43_48_channel_source_vs_oracle(eng, size, monkeypatch):
     assert _md(y, yd) < 2e-5 and _md(y, yd) > 0.0          # (two different kernels ran)
 
 
-C24 = [(16, 16, "elu"), (8, 32, "relu"), (13, 22, "elu"), (37, 50, "elu"), (64, 64, "elu"), (3, 2, "elu"), (256, 256, "elu")]
+C24 = [(16, 16, "elu"), (8, 32, "relu"), (13, 22, "elu"), (37, 50, "elu"), (64, 64, "elu"), (3, 2, "elu"), (2, 2, "elu"), (38, 20, "relu"),
+       (256, 256, "elu")]
 
 
 @pytest.mark.parametrize("case", C24, ids=["%dx%d-%s" % c for c in C24])
 def test_op_conv24_winograd_along_x_vs_oracle(eng, case, monkeypatch):
     """24 -> 24 3x3 stride 1 (conv16 / allconv16 / conv_mask_16, the full-resolution layer in front of every output conv):
-    the raw-tile kernel with F(2,3) along x (se_rtilew.hip; even widths) against the oracle and against the direct raw-tile
-    kernel (SE_RTILE_WX=0) -- heights and widths that are not multiples of the 8 x 16 block, a 2-pixel-wide image (every
+    the persistent raw-tile kernels of se_rtilew.hip -- two-dimensional F(2x2,3x3) (even heights and widths, the default) and
+    F(2,3) along x (even widths) -- against the oracle and against the direct raw-tile kernel (SE_RTILE_WX=0) -- heights and widths that are not multiples of the 8 x 16 block, a 2-pixel-wide image (every
     column a border column), both activations, and the network's own 256 x 256."""
     from oracle import sketchedit_oracle as O
     H, W, act = case
@@ -187,13 +188,17 @@ def test_op_conv24_winograd_along_x_vs_oracle(eng, case, monkeypatch):
     b = synth.uniform(23, "c24.b%s" % (case,), (24,), -0.3, 0.3)
     x = synth.uniform(23, "c24.x%s" % (case,), (2, 24, H, W), -1, 1)
     ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, 1, act)
-    monkeypatch.setenv("SE_RTILE_WX", "1")
+    monkeypatch.setenv("SE_RTILE_WX", "2")              # default: two-dimensional F(2x2,3x3) where the height is even too
+    y2 = eng.gated_conv2d(_cuda(x), w, b, act=act)
+    monkeypatch.setenv("SE_RTILE_WX", "1")              # F(2,3) along x only
     y = eng.gated_conv2d(_cuda(x), w, b, act=act)
-    monkeypatch.setenv("SE_RTILE_WX", "0")
+    monkeypatch.setenv("SE_RTILE_WX", "0")              # direct raw-tile kernel
     yd = eng.gated_conv2d(_cuda(x), w, b, act=act)
     assert tuple(y.shape) == (2, 12, H, W)
-    assert _md(y, ref) < TOL_OP and _md(yd, ref) < TOL_OP
-    assert 0.0 < _md(y, yd) < 2e-5                      # (two different kernels ran)
+    assert _md(y, ref) < TOL_OP and _md(yd, ref) < TOL_OP and _md(y2, ref) < TOL_OP
+    assert 0.0 < _md(y, yd) < 2e-5                      # (different kernels ran)
+    if H % 2 == 0:
+        assert 0.0 < _md(y2, y) < 2e-5
 
 
 WINO48 = [(1, 16, 16, "elu"), (1, 64, 64, "elu"), (2, 16, 24, "relu"), (4, 32, 16, "elu"), (1, 10, 14, "elu"),
