@@ -33,6 +33,24 @@
 
 #include <type_traits>
 
+// Developer aid (-DSE_WINO_TRACE, tools/wino_trace.py runw2): s_memtime stamps of workgroup 0 / waves 0 and 4 at the phase
+// boundaries of the first 16 blocks of rtilew2_kernel.
+#ifdef SE_WINO_TRACE
+__device__ unsigned long long g_rtilew2_trace[2 * 16 * 8];
+extern "C" int se_debug_rtilew2_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rtilew2_trace), sizeof(unsigned long long) * 2 * 16 * 8);
+}
+#define RW2_STAMP(k)                                                                      \
+  do {                                                                                    \
+    if (blockIdx.x == 0 && (w & 3) == 0 && trace_it < 16) {                               \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                         \
+      if (lane == 0) g_rtilew2_trace[((w >> 2) * 16 + trace_it) * 8 + (k)] = t_;          \
+    }                                                                                     \
+  } while (0)
+#else
+#define RW2_STAMP(k)
+#endif
+
 namespace se {
 
 __global__ __launch_bounds__(512, 2) void rtilew_kernel(const RTileParams p) {
@@ -248,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* T = smem;
   char* Wres = smem + TB;
+  char* Ost = smem + TB + 16 * WPOS;             // 12 KB: the block's outputs in their memory layout (16 rows x 16 pixels x 48 B)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,8 +335,8 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
   asm volatile("" : "+v"(neg1));
   const int lanec = (g4 & 1) * 4 + (g4 >> 1) * 2;                    // this lane's channel pair inside the row tile
   const int tle = ct * 16 + jx, tyl = tle >> 3, txl = tle & 7;       // the tile whose outputs this lane holds
-  const unsigned lane_dst = (unsigned)((2 * tyl * p.Win + 2 * txl) * p.G + rt * 8 + lanec) * 4u;      // byte offset inside a block
-  const unsigned dinc_y = (unsigned)(p.Win * p.G) * 4u, dinc_x = (unsigned)p.G * 4u;
+  const int lane_ost = ((2 * tyl * 16 + 2 * txl) * 12 + rt * 8 + lanec) * 4;      // byte offset inside the staged block
+  const unsigned dinc_y = (unsigned)(p.Win * p.G) * 4u;
 
   // ---- prologue: the weights once per workgroup (LDS-DMA), the first block's transformed tiles
   {
@@ -326,16 +345,18 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
   }
   f32x4 d[4][4];
   int blk = blockIdx.x;
-  if (blk < nblk) {
+  if (blk < nblk && w < 6) {
     gather(blk, d);
     transform(d);
   }
   dma_wait_all();
   __syncthreads();
 
-  for (; blk < nblk; blk += gridDim.x) {
+  for (int trace_it = 0; blk < nblk; blk += gridDim.x, ++trace_it) {
     const int nxt = blk + gridDim.x;
-    if (nxt < nblk) gather(nxt, d);              // flies under the MFMA phase
+    RW2_STAMP(0);
+    if (nxt < nblk && w < 6) gather(nxt, d);     // flies under the MFMA phase (waves 6, 7 have no transform task)
+    RW2_STAMP(1);
     int b, ty0, tx0;
     block_origin(blk, b, ty0, tx0);
     f32x4 oy[2][2];                              // the 2 x 2 outputs of this lane's tile: start at the bias
@@ -388,9 +409,9 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    RW2_STAMP(2);
     // ---- epilogue (MIXED): rows 0-7 features (lanes 0-31), rows 8-15 their gates (lane + 32)
     char* dblk = (char*)p.dst + ((size_t)(b * p.Hin + ty0) * p.Win + tx0) * (size_t)(p.G * 4);
-    const int y0 = ty0 + 2 * tyl, x0 = tx0 + 2 * txl;
     const bool okc = rt * 8 + lanec < p.G;
     auto epilogue = [&](auto elu_tag) {
       constexpr bool ELU = decltype(elu_tag)::value;
@@ -406,14 +427,28 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
           float2 ov;
           ov.x = (ELU ? elu_fast(f0) : fmaxf(f0, 0.f)) * sigmoid_fast(gg0);
           ov.y = (ELU ? elu_fast(f1) : fmaxf(f1, 0.f)) * sigmoid_fast(gg1);
-          if (okc && y0 + a < p.Hin && x0 + bb < p.Win)
-            *(float2*)(dblk + (lane_dst + (unsigned)a * dinc_y + (unsigned)bb * dinc_x)) = ov;
+          if (okc) *(float2*)(Ost + lane_ost + a * (16 * 48) + bb * 48) = ov;
         }
     };
     if (p.act == 0) epilogue(std::true_type()); else epilogue(std::false_type());
-    __syncthreads();                             // every wave has read T
+    RW2_STAMP(3);
+    __syncthreads();                             // every wave has read T; the block's outputs are staged
+    RW2_STAMP(4);
+    // the staged outputs leave as 16-byte pieces of contiguous 768-byte rows (the epilogue's own 8-byte stores scattered over
+    // 16 pixels per instruction were ~3000 of a block's 13500 cycles)
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int k = tid + rep * 512;             // piece k: row k / 48, 16-byte piece k % 48 of the row (3 pieces per pixel)
+      if (k < 16 * 48) {
+        const int row = k / 48, pc = k - row * 48;
+        if (ty0 + row < p.Hin && tx0 + pc / 3 < p.Win)
+          *(f32x4*)(dblk + (size_t)row * dinc_y + pc * 16) = *(const f32x4*)(Ost + k * 16);
+      }
+    }
     if (nxt < nblk) transform(d);
+    RW2_STAMP(5);
     __syncthreads();
+    RW2_STAMP(6);
   }
 }
 
@@ -438,7 +473,7 @@ hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
 }
 
 hipError_t launch_rtilew2(const RTileParams& p, hipStream_t st) {
-  constexpr int LDS = 16 * 64 * 96 + 16 * 24 * 128;      // transformed tiles 96 KB + weights 48 KB
+  constexpr int LDS = 16 * 64 * 96 + 16 * 24 * 128 + 16 * 16 * 48;      // transformed tiles 96 KB + weights 48 KB + staged outputs 12 KB
   {
     hipError_t e = ensure_max_lds((const void*)rtilew2_kernel, LDS);
     if (e != hipSuccess) return e;

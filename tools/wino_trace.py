@@ -116,5 +116,35 @@ def run24():
         print("wave %d: prologue %d  loop %d  epilogue %d cycles (s_memtime ticks: 100 MHz)" % (wv * 4, e[1] - e[0], e[2] - e[1], e[3] - e[2]))
 
 
+def runw2():
+    """two-dimensional Winograd kernel of the 24 -> 24 layers (se_rtilew.hip rtilew2_kernel): phases of the first 16 blocks"""
+    os.environ["SKETCHEDIT_HIP_LIB"] = SO
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    from sketchedit_amd import synth
+    from sketchedit_amd._lib import Engine
+    a = 1.5 / np.sqrt(24 * 9)
+    w = synth.uniform(1, "t.w", (24, 24, 3, 3), -a, a)
+    b = synth.uniform(1, "t.b", (24,), -0.1, 0.1)
+    x = torch.from_numpy(synth.uniform(1, "t.x", (32, 24, 256, 256), -1, 1)).cuda()
+    lib = ctypes.CDLL(SO)
+    buf = (ctypes.c_ulonglong * (2 * 16 * 8))()
+    eng = Engine(0)
+    for _ in range(3):
+        eng.gated_conv2d(x, w, b)
+    torch.cuda.synchronize()
+    assert lib.se_debug_rtilew2_trace(buf) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(2, 16, 8).astype(np.int64)
+    names = ["gather", "mfma", "epilogue", "barrier1", "transform", "barrier2"]
+    print("== rtilew2_kernel: block  " + "  ".join("%-9s" % n for n in names) + " total  | wave 4 ...")
+    for it in range(16):
+        row = "%2d   " % it
+        for wv in range(2):
+            dd = [t[wv, it, k + 1] - t[wv, it, k] for k in range(6)]
+            row += "  ".join("%-9d" % v for v in dd) + " %6d  | " % (t[wv, it, 6] - t[wv, it, 0])
+        print(row)
+
+
 if __name__ == "__main__":
-    {"build": build, "run": run, "run48": run48, "run24": run24}[sys.argv[1]]()
+    {"build": build, "run": run, "run48": run48, "run24": run24, "runw2": runw2}[sys.argv[1]]()
