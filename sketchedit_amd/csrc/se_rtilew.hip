@@ -256,7 +256,9 @@ __global__ __launch_bounds__(512, 2) void rtilew_kernel(const RTileParams p) {
 // the transform 13 %, the MFMAs + folds 10 %, the activation arithmetic 6 %; the rest is the serial chain of a block
 // (two barriers, 32 LDS writes, fragment reads, stores) that one workgroup per CU cannot overlap with anything.  Also
 // measured on the one-dimensional form, without effect: gathers two blocks ahead (two register sets), and two 4-wave
-// workgroups per CU with one T buffer each (201 instead of 207 us).
+// workgroups per CU with one T buffer each (201 instead of 207 us).  The 8-byte k-half-1 fragment reads put tiles j and j + 8
+// on the same banks (41 % of the LDS cycles are conflict cycles); the conflict-free alternative -- 16-byte reads in the pattern
+// of k-half 0 with a per-lane element select -- reads twice the bytes and adds 64 selects per block: +15 %, not kept.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
   constexpr int ENT = 96, NTILE = 64;
