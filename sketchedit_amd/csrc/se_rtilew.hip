@@ -454,6 +454,18 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
   }
 }
 
+// CUs of the current device (persistent grids = one workgroup per CU); queried once per device, not per launch
+static int cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
 hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 18 * 3072 + 4 * 3 * 24 * 128;      // two transformed tiles 108 KB + weights 36 KB
   {
@@ -461,12 +473,7 @@ hipError_t launch_rtilew(const RTileParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const int nblk = p.B * p.ty * p.tx;
-  int cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  }
+  const int cus = cu_count();
   const int grid = nblk < cus ? nblk : cus;      // persistent: one workgroup per CU (147 KB of LDS), each walks nblk / grid blocks
   set_launch_grid(grid);
   ProfScope ps_(st, PL_GCONV_N24);
@@ -481,12 +488,7 @@ hipError_t launch_rtilew2(const RTileParams& p, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   const int nblk = p.B * p.ty * p.tx;
-  int cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  }
+  const int cus = cu_count();
   const int grid = nblk < cus ? nblk : cus;
   set_launch_grid(grid);
   ProfScope ps_(st, PL_GCONV_N24);
