@@ -87,6 +87,7 @@ struct Layer {
   float* d_wx = nullptr;      // 24 -> 24 3x3: image of the F(2,3)-along-x raw-tile kernel (se_rtilew.hip)
   float* d_wx2 = nullptr;     //   and of its two-dimensional F(2x2,3x3) form
   float* d_wd = nullptr;      // 5x5 layers with padding channels in their stored input (fp32): dense-K image (se_rtile.hip)
+  float* d_wdw = nullptr;     //   and the image of its F(2,5)-along-x form (rtile_dense5w_kernel)
   int dense = 0, nchd = 0;    //   real channels per pixel (3 or 5), 32-k chunks of the dense image
 };
 
@@ -327,6 +328,31 @@ int pack_layer_dense(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   HIPCHK(c, hipMalloc(&L.d_wd, img.size() * 4));
   HIPCHK(c, hipMemcpy(L.d_wd, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   L.dense = Cd; L.nchd = nch;
+  // F(2,5)-along-x form (rtile_dense5w_kernel): U[nu][ky][c] = sum_kx Gx[nu][kx] w[ky][kx]; one chunk per position with
+  // k = ky * Cd + c in the same instruction-major order
+  {
+    static const double Gx[6][5] = {{1. / 4, 0., 0., 0., 0.}, {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6},
+                                    {1. / 24, 1. / 12, 1. / 6, 1. / 3, 2. / 3}, {1. / 24, -1. / 12, 1. / 6, -1. / 3, 2. / 3}, {0., 0., 0., 0., 1.}};
+    std::vector<float> imw((size_t)6 * NP * 32, 0.f);
+    for (int n = 0; n < NP; ++n) {
+      const int oc = out_channel_of_row(GC_N48, n, G, d.cout);
+      if (oc < 0) continue;
+      for (int j = 0; j < 5 * Cd; ++j) {
+        const int ky = j / Cd, ic = cin_map[j % Cd];
+        const float* g = &L.w[(((size_t)oc * d.cin + ic) * 5 + ky) * 5];
+        const int step = j / 4, gq = j % 4, kin = (step / 4) * 16 + gq * 4 + (step % 4);
+        const int s_ = kin / 4, e = kin % 4, ps = s_ ^ ((n >> 1) & 7);
+        for (int nu = 0; nu < 6; ++nu) {
+          double u = 0.;
+          for (int kx = 0; kx < 5; ++kx) u += Gx[nu][kx] * (double)g[kx];
+          imw[((size_t)nu * NP + n) * 32 + ps * 4 + e] = (float)u;
+        }
+      }
+    }
+    if (L.d_wdw) (void)hipFree(L.d_wdw);
+    HIPCHK(c, hipMalloc(&L.d_wdw, imw.size() * 4));
+    HIPCHK(c, hipMemcpy(L.d_wdw, imw.data(), imw.size() * 4, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -900,6 +926,15 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
       p.ty = (Hin + 7) / 8; p.tx = (Win + 15) / 16;
       p.act = d.act; p.xcd = xcd_remap_enabled(); p.dense = L.dense; p.nch = L.nchd; p.NP = 48;
       const double alg = 2.0 * (double)nb * Ho * Wo * d.cout * d.cin * 25;
+      // F(2,5) along x (rtile_dense5w_kernel; even widths): 6 positions x ceil(5 Cd / 4) k-steps per 2 outputs.  SE_RTILE_D5W=0: direct
+      const char* d5w_env = getenv("SE_RTILE_D5W");      // (read per call: the tests compare both forms in one process)
+      if (!(d5w_env && atoi(d5w_env) == 0) && L.d_wdw && (Win % 2) == 0) {
+        p.wpk = L.d_wdw; p.dense = L.dense + 100;
+        set_launch_cost(alg, 4.0 * ((double)nb * Hin * Win * d.cin + (double)nb * Ho * Wo * (d.cout / 2)), d.name,
+                        (double)nb * p.ty * p.tx * 4.0 * (6.0 * ((5 * L.dense + 3) / 4) * 3.0) * 2048.0);
+        HIPCHK(c, launch_rtile(p, c->st));
+        continue;
+      }
       set_launch_cost(alg, 4.0 * ((double)nb * Hin * Win * d.cin + (double)nb * Ho * Wo * (d.cout / 2)), d.name,
                       2.0 * (double)nb * Hin * Win * 48.0 * (4.0 * ((25 * L.dense + 3) / 4)));       // ceil(K / 4) k-steps of 4
       HIPCHK(c, launch_rtile(p, c->st));
@@ -1671,6 +1706,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_w16s) (void)hipFree(kv.second.d_w16s);
       if (kv.second.d_w96) (void)hipFree(kv.second.d_w96);
       if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
+      if (kv.second.d_wdw) (void)hipFree(kv.second.d_wdw);
       if (kv.second.d_u1) (void)hipFree(kv.second.d_u1);
       if (kv.second.d_wv) (void)hipFree(kv.second.d_wv);
       if (kv.second.d_wv16) (void)hipFree(kv.second.d_wv16);
@@ -1684,6 +1720,7 @@ void se_destroy(se_ctx* c) {
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
   if (c->wconv1_j4.d_w16) (void)hipFree(c->wconv1_j4.d_w16);
   if (c->wconv1_j4.d_wd) (void)hipFree(c->wconv1_j4.d_wd);
+  if (c->wconv1_j4.d_wdw) (void)hipFree(c->wconv1_j4.d_wdw);
   if (c->zeros) (void)hipFree(c->zeros);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
   drop_graphs(c);
@@ -2050,6 +2087,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_w16s) (void)hipFree(L.d_w16s);
   if (L.d_w96) (void)hipFree(L.d_w96);
   if (L.d_wd) (void)hipFree(L.d_wd);
+  if (L.d_wdw) (void)hipFree(L.d_wdw);
   if (L.d_u1) (void)hipFree(L.d_u1);
   if (L.d_wv) (void)hipFree(L.d_wv);
   if (L.d_wv16) (void)hipFree(L.d_wv16);

@@ -330,6 +330,160 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 5x5 first layers with a ONE-DIMENSIONAL Winograd transform, F(2,5) along x (round 4; even widths).  These
+// kernels are bound by the fp32 MFMA pipe (with every second k-step removed a launch is 34 % shorter), so the multiply-adds
+// themselves go: 6 (position, kernel row) products per 2 outputs and kernel row instead of 10.
+//   out[y][2t + o] = sum_ky sum_c A^T[o][nu] ( U[nu][ky][c] * V[y + ky - 2][t][nu][c] ),   V = B^T x[r][2t - 2 .. 2t + 3]
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (that of F(4,3))
+//   G   = [1/4 0 0 0 0; -1/6 (1 1 1 1 1); -1/6 (1 -1 1 -1 1); 1/24 (1 2 4 8 16); 1/24 (1 -2 4 -8 16); 0 0 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 1]
+// The dense raw tile is staged as before; a transform pass (LDS -> LDS, <= 2 tasks of 6 reads, 12 fmas, 6 writes per thread)
+// builds T[row][nu][x-tile][CD], and the k loop of a position nu is the dense kernel's with K = 5 CD in ONE chunk
+// (k = ky * CD + c, instruction-major, exactly ceil(K / 4) k-steps) and the 16 MFMA columns = 2 rows x 8 x-tiles.
+// MFMAs per wave and 8 x 16 block: 72 / 90 / 126 for 3 / 4 / 5 channels (dense direct: 114 / 150 / 192).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CD>
+__global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams p) {
+  constexpr int NT = 3, TR = 8, KH = 5;
+  constexpr int RH = TR + KH - 1, RW = 20;                 // raw tile: 12 x 20 source pixels (columns tx0 - 2 .. tx0 + 17)
+  constexpr int NDW = RH * RW * CD;
+  constexpr int K = KH * CD, KS = (K + 3) / 4;             // k per position, MFMA k-steps per position
+  constexpr int TNU = 8 * CD * 4;                          // bytes of the eight x-tiles of one (row, nu)
+  constexpr int TROW = 6 * TNU;                            // bytes of one source row of T
+  constexpr int RAWB = (NDW * 4 + 1023) & ~1023;
+  constexpr int TBYTES = (RH * TROW + 255) & ~255;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Raw = smem;
+  char* T = smem + RAWB;
+  int* Tab = (int*)(smem + RAWB + TBYTES);                 // [32] byte offset inside T of the (kernel row, channel) of chunk slot kin
+  char* Wres = smem + RAWB + TBYTES + 128;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float eluw = p.act == 0 ? 1.f : 0.f;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = p.xcd ? xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = tile / (p.ty * p.tx), t2 = tile - b * (p.ty * p.tx);
+  const int ty0 = (t2 / p.tx) * TR, tx0 = (t2 % p.tx) * 16;
+  const int pixb = p.C * 4;
+
+  const unsigned lds_raw = lds_addr_of(Raw), lds_w = lds_addr_of(Wres);
+  {
+    for (int i = w; i < 6 * 48 / 8; i += 4) glds16_s(p.wpk + (size_t)i * 256, (unsigned)lane * 16u, lds_w + i * 1024);
+    const se_i32x4 rsrc = make_rsrc(p.src, (unsigned)p.B * p.Hin * p.Win * (unsigned)pixb);
+    for (int i = w; i * 64 < NDW; i += 4) {
+      const int q = i * 64 + lane;
+      const int pix = q / CD, ch = q - pix * CD;
+      const int row = pix / RW, col = pix - row * RW;
+      const int sy = ty0 - 2 + row, sx = tx0 - 2 + col;
+      const bool ok = q < NDW && (unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win;
+      const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)ch * 4u;
+      bufdma4(ok ? off : 0x80000000u, rsrc, lds_raw + i * 256);
+    }
+    if (tid < 32) {      // chunk slot -> (kernel row, channel): inverse of dense_kin (pack_layer_dense5w); padding slots: any valid offset
+      const int half = tid >> 4, g = (tid >> 2) & 3, r = tid & 3;
+      int j = (half * 4 + r) * 4 + g;
+      if (j >= K) j = K - 1;
+      const int ky = j / CD, c = j - ky * CD;
+      Tab[tid] = ky * TROW + c * 4;
+    }
+  }
+  dma_wait_all();
+  __syncthreads();
+  // ---- transform pass: task = (row, x-tile, channel); x-tile t reads raw columns 2t .. 2t + 5 (= source tx0 + 2t - 2 .. + 3)
+  for (int k = tid; k < RH * 8 * CD; k += 256) {
+    const int row = k / (8 * CD), rem = k - row * (8 * CD), xt = rem / CD, c = rem - xt * CD;
+    const float* src = (const float*)(Raw + ((row * RW + 2 * xt) * CD + c) * 4);
+    const float d0 = src[0], d1 = src[CD], d2 = src[2 * CD], d3 = src[3 * CD], d4 = src[4 * CD], d5 = src[5 * CD];
+    const float pp = fmaf(-4.f, d2, d4), qq = fmaf(-4.f, d1, d3), rr = d4 - d2, tt = d3 - d1;
+    float* dst = (float*)(T + row * TROW + xt * CD * 4 + c * 4);
+    dst[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    dst[TNU / 4] = pp + qq;
+    dst[2 * TNU / 4] = pp - qq;
+    dst[3 * TNU / 4] = fmaf(2.f, tt, rr);
+    dst[4 * TNU / 4] = fmaf(-2.f, tt, rr);
+    dst[5 * TNU / 4] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+  }
+  __syncthreads();
+
+  int off0, off1;
+  frag_offsets(lane, off0, off1);
+  const int jx = lane & 15, g4 = lane >> 4;
+  const int rl = jx >> 3, xt = jx & 7;
+  const int xbase = (2 * w + rl) * TROW + xt * CD * 4;
+  // this lane group's four (k-half 0) + four (k-half 1) element offsets
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 to0 = *(const i32x4*)(Tab + g4 * 4), to1 = *(const i32x4*)(Tab + 16 + g4 * 4);
+  f32x4 oy[2][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) oy[0][nt] = oy[1][nt] = *(const f32x4*)(p.bias + nt * 16 + g4 * 4);
+  float neg1 = -1.f, two = 2.f, neg2 = -2.f;
+  asm volatile("" : "+v"(neg1), "+v"(two), "+v"(neg2));
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) {
+    f32x4 wq[2][NT], xb[2];
+#pragma unroll
+    for (int half = 0; half < (KS > 4 ? 2 : 1); ++half) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wq[half][nt] = *(const f32x4*)(Wres + nu * (48 * 128) + nt * 2048 + (half ? off1 : off0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xb[half][e] = *(const float*)(T + xbase + nu * TNU + (half ? to1[e] : to0[e]));
+    }
+    f32x4 am[NT];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 cin = s_ == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : am[nt];
+        am[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s_ / 4][nt][s_ % 4], xb[s_ / 4][s_ % 4], cin, 0, 0, 0);
+      }
+    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 1]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nu < 5) oy[0][nt] += am[nt];
+      if (nu == 1 || nu == 5) oy[1][nt] += am[nt];
+      if (nu == 2) oy[1][nt] = am[nt] * neg1 + oy[1][nt];
+      if (nu == 3) oy[1][nt] = am[nt] * two + oy[1][nt];
+      if (nu == 4) oy[1][nt] = am[nt] * neg2 + oy[1][nt];
+    }
+  }
+
+  // ---- epilogue (MIXED rows, two v_permlane32_swap per quad): lane = (row 2w + rl, x-tile xt), outputs x = 2 xt, 2 xt + 1
+  const int q = lane >> 4;
+  const int yy = ty0 + 2 * w + rl;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c0 = nt * 8 + (q & 1) * 4 + (q >> 1) * 2;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int xx = tx0 + 2 * xt + o;
+      const f32x4 v = oy[o][nt];
+      const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+      const float f0 = __uint_as_float(s02[0]), gg0 = __uint_as_float(s02[1]);
+      const float f1 = __uint_as_float(s13[0]), gg1 = __uint_as_float(s13[1]);
+      float2 ov;
+      ov.x = act_fast(f0, eluw) * sigmoid_fast(gg0);
+      ov.y = act_fast(f1, eluw) * sigmoid_fast(gg1);
+      if (c0 < p.G && yy < p.Hin && xx < p.Win)
+        *(float2*)(p.dst + ((size_t)(b * p.Hin + yy) * p.Win + xx) * p.G + c0) = ov;
+    }
+  }
+}
+
+template <int CD>
+static hipError_t launch_rtile_dense5w(const RTileParams& p, hipStream_t st) {
+  constexpr int NDW = 12 * 20 * CD;
+  constexpr int LDS = ((NDW * 4 + 1023) & ~1023) + ((12 * 6 * 8 * CD * 4 + 255) & ~255) + 128 + 6 * 48 * 128;
+  hipError_t e = ensure_max_lds((const void*)rtile_dense5w_kernel<CD>, 80 * 1024);
+  if (e != hipSuccess) return e;
+  const int tiles = p.B * p.ty * p.tx;
+  set_launch_grid(tiles);
+  ProfScope ps_(st, PL_GCONV_N48);
+  hipLaunchKernelGGL((rtile_dense5w_kernel<CD>), dim3(tiles), dim3(256), LDS, st, p);
+  return hipGetLastError();
+}
+
 template <int CD>
 static hipError_t launch_rtile_dense5(const RTileParams& p, hipStream_t st) {
   constexpr int NDW = 12 * 20 * CD, K = 25 * CD, NCH = (K + 31) / 32;
@@ -364,6 +518,9 @@ static hipError_t launch_rtile_t(const RTileParams& p, hipStream_t st, int label
 int rtile_rows(bool bf16) { return bf16 ? 32 : 8; }
 
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st) {
+  if (p.dense == 103) return launch_rtile_dense5w<3>(p, st);      // dense + 100: the F(2,5)-along-x form (wpk = image of pack_layer_dense5w)
+  if (p.dense == 104) return launch_rtile_dense5w<4>(p, st);
+  if (p.dense == 105) return launch_rtile_dense5w<5>(p, st);
   if (p.dense == 3) return launch_rtile_dense5<3>(p, st);
   if (p.dense == 4) return launch_rtile_dense5<4>(p, st);
   if (p.dense == 5) return launch_rtile_dense5<5>(p, st);

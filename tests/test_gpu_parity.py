@@ -352,6 +352,31 @@ def test_op_first_layer_dense_k_vs_oracle(eng, case, monkeypatch):
     assert _md(y2, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("case", [(5, 22, 18), (3, 22, 18), (4, 22, 18), (5, 8, 16), (3, 40, 34), (4, 16, 48), (5, 9, 70), (3, 5, 2), (4, 256, 256)],
+                         ids=lambda c: "c%d-%dx%d" % c)
+def test_op_first_layer_winograd_along_x_vs_oracle(eng, case, monkeypatch):
+    """The 5x5 first layers with F(2,5) along x (se_rtile.hip rtile_dense5w_kernel; even widths; non-dyadic constants 1/6,
+    1/24, 2/3) against the oracle and against the dense direct kernel (SE_RTILE_D5W=0): 3, 4 and 5 real channels, ragged
+    blocks, a 2-pixel-wide image, the network's 256 x 256; and at |x| up to 8 with a relative bound."""
+    from oracle import sketchedit_oracle as O
+    cin, H, W = case
+    a = 1.5 / np.sqrt(cin * 25)
+    w = synth.uniform(59, "d5w.w%s" % (case,), (48, cin, 5, 5), -a, a)
+    b = synth.uniform(59, "d5w.b%s" % (case,), (48,), -0.3, 0.3)
+    x = synth.uniform(59, "d5w.x%s" % (case,), (2, cin, H, W), -1, 1)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu")
+    monkeypatch.setenv("SE_RTILE_D5W", "1")
+    y = eng.gated_conv2d(_cuda(x), w, b)
+    monkeypatch.setenv("SE_RTILE_D5W", "0")
+    yd = eng.gated_conv2d(_cuda(x), w, b)
+    assert _md(y, ref) < TOL_OP and _md(yd, ref) < TOL_OP
+    assert 0.0 < _md(y, yd) < 3e-5                      # (two different kernels ran)
+    monkeypatch.setenv("SE_RTILE_D5W", "1")
+    y8 = eng.gated_conv2d(_cuda(x * 8.0), w, b)
+    ref8 = O.gated_conv(torch.from_numpy(x * 8.0), torch.from_numpy(w), torch.from_numpy(b), 1, 1, "elu")
+    assert _md(y8, ref8) < TOL_OP * max(1.0, float(ref8.abs().max()))
+
+
 def test_op_first_layer_dense_k_oversized_batch_keeps_the_kernel_form(eng, monkeypatch):
     """a batch whose first-layer input exceeds the kernel's 32-bit byte offsets runs as sub-launches of the SAME
     dense-K kernel (not the channel-padded one, which sums in another order): forced here with a small byte limit
