@@ -342,6 +342,9 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
 // builds T[row][nu][x-tile][CD], and the k loop of a position nu is the dense kernel's with K = 5 CD in ONE chunk
 // (k = ky * CD + c, instruction-major, exactly ceil(K / 4) k-steps) and the 16 MFMA columns = 2 rows x 8 x-tiles.
 // MFMAs per wave and 8 x 16 block: 72 / 90 / 126 for 3 / 4 / 5 channels (dense direct: 114 / 150 / 192).
+// Measured (256x256 B=32, same box): gconv_n48 1.85 -> 1.76 ms per step.  A PERSISTENT form (two workgroups per CU, weights
+// resident once, the raw tile of block i+1 DMA'd under the MFMAs of block i) measured the same 1.754 ms and was dropped:
+// with two non-persistent workgroups per CU the other workgroup's MFMAs already cover this one's prologue.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CD>
 __global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams p) {
