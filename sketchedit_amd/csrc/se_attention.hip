@@ -1013,6 +1013,182 @@ __global__ __launch_bounds__(256) void att2_ptilde1_kernel(const AttParams p) {
   }
 }
 
+// att2_ptilde_lds_kernel (round 4): the same pass with its source rows staged in LDS.  att2_ptilde4_kernel
+// forms every S[q][k] four times (once per output it feeds) from nine source rows per output row, and is bound by the
+// L2 -> L1 traffic of those rows.  Here a workgroup owns a 4 x 4 PATCH of class-grid positions r = (ry0 + a, rx0 + bx) and
+// sweeps the key axis in chunks of C = 128 columns:
+//   stage  : the 6 x 6 source rows E[(ry0 - 1 + i') wc + rx0 - 1 + j'][s0 .. s0 + C + wc + 4) and the chunk's slice of the key
+//            tables, by LDS-DMA (36 rows for 16 output rows instead of 9 per row: 2.25 + halo E elements per output through
+//            the vector-memory path instead of 9)
+//   phase B: P[q][k] for the 5 x 5 queries q = r - d that own a patch over one of the 16 positions, ONCE each (25 / 16 = 1.6
+//            exponentials per output instead of 4), written to a ring of 256 columns per query (P~[r][s] only needs columns
+//            s - wc - 1 .. s, all to the left: the ring keeps the tail of the previous chunk, no halo is recomputed)
+//   phase C: P~[r][s] = sum_d P[r - d][s - d] from the ring, 16-byte non-temporal stores
+// Ten waves: eight consumers (phases B, C) and TWO PRODUCER waves that issue every DMA.  A first version had all waves issue
+// their share of the stage after phase B and wait vmcnt(0) before the next: one stage (28 KB) in flight for one phase C --
+// far less than bandwidth x latency; it measured 335 us at 512x512 B=8 (round-3 kernel: 410).  Stores share vmcnt with loads
+// on gfx9 and complete out of order with them, so a wave that stores cannot use a counted wait; a producer wave issues
+// loads only, keeps NS - 1 stages in flight behind the one being consumed and waits vmcnt((NS - 2) x its instructions per
+// stage).  One producer (63 instructions in flight at most: the vmcnt counter) measured 278 us; ablations of that version
+// (same box): DMA + barriers alone 174 us = 3.1 TB/s of E -- latency x bytes in flight, not HBM -- phase B +36, phase C +51.
+// A phase-B task is (query ROW i, column pair): the 12 source rows (i .. i+1, 0 .. 5) are read once for the five queries
+// (i, 0 .. 4) -- 14 instead of 36 bytes of LDS traffic per P value.
+// Expression, summation order and key test are those of att2_ptilde4_kernel (results agree to 1 ulp); a query that does not
+// exist carries -inf / 0, so the clamped or wrapped source rows it reads (finite) give exactly 0.
+// Needs wc % 4 == 0 (aligned 16-byte LDS reads at column shift wc) and wc <= 124 (ring of 256 >= C + wc + 4).
+// NIP = 1 KB DMA instructions per stage (the 36 x (C + wc + 4) / 4 sixteen-byte pieces, flat), a compile-time bound -- the
+// counted wait needs an immediate: 28 (wc <= 64: NS = 4 stages of 29 KB, 142 KB of LDS) or 36 (wc <= 124: NS = 3).
+template <bool BF16, int NIP, int NS>
+__global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p, int npy, int npx) {
+  constexpr int C = 128, NG = C / 4, RING = 256;
+  constexpr int ES = BF16 ? 2 : 4;
+  constexpr int SB = (NIP + 1) * 1024;                     // one stage: E pieces + (kmul, kadd) slice
+  constexpr int NH = NIP / 2;                              // E instructions per producer wave and stage
+  static_assert((NS - 2) * (NH + 1) <= 63, "vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int WS = C + p.wc + 4, NPR = WS >> 2;              // staged columns per source row; 16-byte pieces per row
+  const int NPT = 36 * NPR;                                // E pieces of a stage (<= NIP * 64)
+  float* Pr = (float*)(smem + NS * SB);                    // [25][RING]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lb = xcd_tile(blockIdx.x, gridDim.x);
+  const int b = lb / (npy * npx), rem = lb - b * (npy * npx);
+  const int py = rem / npx, px = rem - py * npx;
+  const int ry0 = 4 * py, rx0 = 4 * px;
+  const int nchunks = (p.Rp + C - 1) / C;
+
+  if (w >= 8) {
+    // ---------------- producer waves: instruction k = 2 m + pid of a stage covers pieces k * 64 .. + 63
+    const int pid = w - 8;
+    const int r00 = (ry0 - 1) * p.wc + rx0 - 1;            // source row (i', j') = r00 + i' wc + j' (linear, as r + dl in att2_ptilde4_kernel)
+    const se_i32x4 rsE = make_rsrc(p.E + (size_t)b * p.R * p.Rp, (unsigned)p.R * (unsigned)p.Rp * 4u);
+    unsigned goff[NH];                                     // piece -> byte offset inside the image's E
+    {
+      // row = pi / NPR without an integer division per piece: pieces advance by 128 per instruction of this wave
+      int pi = pid * 64 + lane;
+      int row = pi / NPR, cc = pi - row * NPR;
+      const int drow = 128 / NPR, dcc = 128 - drow * NPR;
+#pragma unroll
+      for (int m = 0; m < NH; ++m) {
+        const int i = row / 6, j = row - i * 6;
+        const int er = min(max(r00 + i * p.wc + j, 0), p.R - 1);
+        goff[m] = pi < NPT ? (unsigned)er * (unsigned)p.Rp * 4u + (unsigned)cc * 16u : 0x80000000u;      // padding pieces: zeros
+        pi += 128; row += drow; cc += dcc;
+        if (cc >= NPR) { cc -= NPR; row += 1; }
+      }
+    }
+    const float* ktab = (lane < 32 ? p.kmul : p.kadd) + (size_t)b * p.Rp;
+    const int kl = 4 * (lane & 31);
+    const unsigned lds_e = lds_addr_of(smem);
+    auto issue = [&](int n) {
+      const unsigned base = lds_e + (unsigned)(n % NS) * SB + pid * 1024;
+      const unsigned s0b = (unsigned)(n * C) * 4u;
+#pragma unroll
+      for (int m = 0; m < NH; ++m) bufdma16(__builtin_elementwise_add_sat(goff[m], s0b), rsE, base + m * 2048);
+      if (pid == 0) glds16(ktab + min(n * C + kl, p.Rp - 4), lds_e + (unsigned)(n % NS) * SB + NIP * 1024);      // [kmul 128][kadd 128]
+    };
+#pragma unroll
+    for (int n = 0; n < NS - 1; ++n)
+      if (n < nchunks) issue(n);
+    for (int n = 0; n < nchunks; ++n) {
+      const int y = min(NS - 2, nchunks - 1 - n);          // stages younger than n in flight
+      if (y >= NS - 2) {
+        if (pid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (NH + 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NH) : "memory");
+      } else if (NS == 4 && y == 1) {
+        if (pid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();               // top: stage n is complete (consumers: done with phase C of n - 1)
+#ifndef PT_NODMA
+      if (n + NS - 1 < nchunks) issue(n + NS - 1);         // into the buffer of stage n - 1 (phase B of n - 1 ended before its mid barrier)
+#endif
+      __syncthreads();               // mid
+    }
+    return;
+  }
+
+  // ---------------- consumer waves (512 threads)
+  // ring zeroed (columns < 0 are not keys: P = 0)
+  for (int i = tid; i < 25 * RING / 4; i += 512) ((f32x4*)Pr)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // phase-B role: waves 0..4 = query row i, lane = column pair; the five queries (i, 0..4): -m2 (or -inf), 1 / l (or 0)
+  float qm[5], qi[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int qy = ry0 - 1 + w, qx = rx0 - 1 + j;
+    const bool ok = w < 5 && qy >= 0 && qy < p.hs && qx >= 0 && qx < p.ws;
+    const float2 st = *(const float2*)(p.stats + ((size_t)b * p.R + (ok ? qy * p.wc + qx : 0)) * 2);
+    qm[j] = ok ? -st.x : -INFINITY;
+    qi[j] = ok ? st.y : 0.f;
+  }
+  for (int n = 0; n < nchunks; ++n) {
+    const int s0 = n * C;
+    const float* Eb = (const float*)(smem + (n % NS) * SB);
+    const float* Kt = (const float*)(smem + (n % NS) * SB + NIP * 1024);
+    __syncthreads();                 // top
+    // ---- phase B
+#ifndef PT_NOB
+    if (w < 5) {
+      const int c = 2 * lane, s = s0 + c;
+      f32x2 r0[6], r1[6];
+      float x0[6], x1[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float* e0 = Eb + (w * 6 + j) * WS + c;           // (i, j')      columns c, c + 1 | c + 2
+        const float* e1 = e0 + 6 * WS + p.wc;                  // (i + 1, j')  columns c + wc, c + wc + 1 | c + wc + 2
+        r0[j] = *(const f32x2*)e0; x0[j] = e0[2];
+        r1[j] = *(const f32x2*)e1; x1[j] = e1[2];
+      }
+      const f32x2 mu = *(const f32x2*)(Kt + c), ad = *(const f32x2*)(Kt + C + c);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        // S[(i, j)][k] = ((E[(i,j)][k] + E[(i,j+1)][k+1]) + E[(i+1,j)][k+wc]) + E[(i+1,j+1)][k+wc+1]
+        const f32x2 sum = ((r0[j] + (f32x2){r0[j + 1][1], x0[j + 1]}) + r1[j]) + (f32x2){r1[j + 1][1], x1[j + 1]};
+        const f32x2 arg = sum * mu + (ad + (f32x2){qm[j], qm[j]});
+        f32x2 pv = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} * (f32x2){qi[j], qi[j]};
+        if (BF16) {                                            // P is a bf16 value in bf16 mode (rounded before the sum)
+          const unsigned u = pack_bf16x2(pv[0], pv[1]);
+          pv = (f32x2){bf16_lo(u), bf16_hi(u)};
+        }
+        if (s >= p.Rp) pv = (f32x2){0.f, 0.f};
+        *(f32x2*)(Pr + (w * 5 + j) * RING + (s & (RING - 1))) = pv;
+      }
+    }
+#endif
+    __syncthreads();                 // mid: the ring holds this chunk; the stage buffer is free
+    // ---- phase C: task = (output position o of the patch, group g of four columns)
+#ifndef PT_NOC
+    {
+      const int o = tid / NG, g = tid - o * NG;
+      const int a = o >> 2, bx = o & 3;
+      const int s = s0 + 4 * g;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dy = d >> 1, dx = d & 1;
+        const float* row = Pr + ((a + 1 - dy) * 5 + (bx + 1 - dx)) * RING;
+        const int cb = (s - dy * p.wc) & (RING - 1);
+        const f32x4 v = *(const f32x4*)(row + cb);
+        if (dx == 0) acc += v;
+        else acc += (f32x4){row[(cb - 1) & (RING - 1)], v[0], v[1], v[2]};
+      }
+      if (ry0 + a < p.hc && s < p.Rp) {
+        const int r = (ry0 + a) * p.wc + rx0 + bx;
+        char* out = (char*)p.P + (((size_t)b * p.R + r) * p.Rp + s) * ES;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#ifdef PT_NOSTORE
+        if (acc[0] == 12345.f)
+#endif
+        {
+          if (BF16) __builtin_nontemporal_store((u32x2){pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])}, (u32x2*)out);
+          else __builtin_nontemporal_store(acc, (f32x4*)out);
+        }
+      }
+    }
+#endif
+  }
+}
+
 // out[b, 2r + cls, c] = sum_s P~[r][s] * xT[cls][c][s]: A tile = NT * 16 channel rows x 32 keys, MFMA columns = class-grid pixels.
 // <PT = 4, NT = 6>: 256 pixels x all 96 channels per workgroup (large batches).  <PT = 1, NT = 3>: 64 pixels x one half of
 // the channels -- 8x the workgroups for calls whose grid would otherwise leave most of the 256 CUs idle (one 256x256
@@ -1112,28 +1288,33 @@ __global__ void att2_similar_kernel(const AttParams p) {
   p.similar[idx] = BF16 ? bf16_lo(((const unsigned short*)p.P)[at]) : p.P[at];
 }
 
-// Which form runs (measured on MI355X, round 3, profiles/r03_*):
-//   256x256 inputs (R = 1024):  fused 44 + 100 us  vs  three-pass 75 + 76 us  per 32 images   -> fused
-//   512x512 inputs (R = 4096):  fused 189 + 426 us vs  three-pass 282 + 285 us per 8 images   -> three-pass (the fused pass
-//       moves 0.4 GB less through HBM -- 3.6 instead of 4.0 GB per step -- but is bound by the L2 -> L1 traffic of its nine
-//       source rows per output row; an LDS-staged tile form is what would fix that, not built)
-//   bf16: P is bf16 there, so the fused form saves no bytes (E is read twice instead of E + P once each) and measured slower.
-// SE_ATT_FUSED=0 / 1 forces the three-pass / fused form in fp32 (default: fused for R <= 1024); SE_ATT_FUSED_BF16=1 extends the
-// choice to bf16 mode.
-static bool att_fused(bool bf16, int Rp) {
-  // (read per call, not cached: the tests switch forms inside one process)
+// Which form runs (measured on MI355X; same-box A/B runs of round 4, tools/_build/att_ab.sh):
+//   256x256 inputs (R = 1024), 32 images:  three-pass 65 + 71 us | fused, round-3 kernels 44 + 89 us | fused, LDS-staged 44 + 81 us
+//   512x512 inputs (R = 4096),  8 images:  three-pass 272 + 269 us | round-3 fused 183 + 410 us     | LDS-staged 184 + 263 us
+//       (the round-3 streaming kernel was bound by the L2 -> L1 traffic of its nine source rows per output row; the LDS-staged
+//       kernel reads and writes HBM at 4.1 TB/s: 1.07 GB in 263 us)
+//   bf16 (512x512, 16 images): three-pass 452 + 275 us | LDS-staged fused 349 + 457 us: P is bf16 there, so the fused form saves
+//       no bytes (E, fp32, is read twice instead of E + P once each) -> three-pass.
+// fp32 default: fused wherever the LDS-staged kernel applies (wc % 4 == 0, wc <= 124) and for R <= 1024.  SE_ATT_FUSED=0 / 1
+// forces the three-pass / fused form; SE_ATT_FUSED_BF16=1 extends the choice to bf16 mode; SE_ATT_PTILDE_LDS=0 keeps the
+// round-3 streaming kernel inside the fused form.  (Read per call, not cached: the tests switch forms inside one process.)
+static bool att_lds_form(int wc) {
+  const char* e = getenv("SE_ATT_PTILDE_LDS");
+  return wc % 4 == 0 && wc <= 124 && !(e && atoi(e) == 0);
+}
+static bool att_fused(bool bf16, int Rp, int wc) {
   const char* e1 = getenv("SE_ATT_FUSED");
   const char* e2 = getenv("SE_ATT_FUSED_BF16");
   const int f32mode = e1 ? (atoi(e1) != 0 ? 1 : 0) : -1;
   const bool bfon = e2 ? atoi(e2) != 0 : SE_ATT_FUSED_BF16_DEFAULT;
   if (bf16 && !bfon) return false;
-  return f32mode < 0 ? Rp <= 1024 : f32mode == 1;
+  return f32mode < 0 ? (Rp <= 1024 || att_lds_form(wc)) : f32mode == 1;
 }
 
 template <bool BF16>
 static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
   AttParams p = p0;
-  const bool fused = att_fused(BF16, p.Rp) && !p.similar && p.stats;      // `similar_out` is P itself: three-pass form
+  const bool fused = att_fused(BF16, p.Rp, p.wc) && !p.similar && p.stats;      // `similar_out` is P itself: three-pass form
   p.Pt = fused ? p.P : p.E;
   {
     const long n = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);
@@ -1183,7 +1364,22 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       const long rows = tile_order_count(p.B, p.hc, p.wc);
       ProfScope ps_(st, PL_ATT_BOXSUM);
       const dim3 grid((unsigned)((rows + 3) / 4));
-      if (p.wc % 4 == 0) hipLaunchKernelGGL((att2_ptilde4_kernel<BF16>), dim3((unsigned)((rows + 7) / 8)), dim3(512), 0, st, p);
+      const bool lds_form = att_lds_form(p.wc);
+      if (lds_form) {
+        const int npy = (p.hc + 3) / 4, npx = p.wc / 4;
+        const dim3 g((unsigned)(p.B * npy * npx));
+        if (p.wc <= 64) {
+          constexpr int lds = 4 * 29 * 1024 + 25 * 256 * 4;
+          hipError_t e = ensure_max_lds((const void*)att2_ptilde_lds_kernel<BF16, 28, 4>, lds);
+          if (e != hipSuccess) return e;
+          hipLaunchKernelGGL((att2_ptilde_lds_kernel<BF16, 28, 4>), g, dim3(640), lds, st, p, npy, npx);
+        } else {
+          constexpr int lds = 3 * 37 * 1024 + 25 * 256 * 4;
+          hipError_t e = ensure_max_lds((const void*)att2_ptilde_lds_kernel<BF16, 36, 3>, lds);
+          if (e != hipSuccess) return e;
+          hipLaunchKernelGGL((att2_ptilde_lds_kernel<BF16, 36, 3>), g, dim3(640), lds, st, p, npy, npx);
+        }
+      } else if (p.wc % 4 == 0) hipLaunchKernelGGL((att2_ptilde4_kernel<BF16>), dim3((unsigned)((rows + 7) / 8)), dim3(512), 0, st, p);
       else hipLaunchKernelGGL((att2_ptilde1_kernel<BF16>), grid, dim3(256), 0, st, p);
     }
   } else {

@@ -411,12 +411,16 @@ def test_op_attention_soft_scores_vs_oracle(eng, shape):
 
 
 @pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 24, 40), (2, 64, 64), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
+@pytest.mark.parametrize("shape", [(2, 16, 12), (2, 16, 16), (1, 24, 40), (2, 64, 64), (1, 128, 128), (1, 132, 136), (1, 20, 248)],
+                         ids=lambda s: "%dx%dx%d" % s)
 def test_op_attention_fused_streaming_pass(eng, shape, bf16, monkeypatch):
     """The fused form of the two streaming passes (att2_stats_kernel + att2_ptilde*_kernel: P is never written) against the
     oracle AND against the three-pass form, forced on at every size: 16x12 (wc = 6: element-load kernel), 16x16 / 24x40 /
-    64x64 (packed four-column kernel; 64x64 is the 256x256-input size where it is the default), 132x136 (rows that do not
-    fit in registers: two-sweep statistics).  Soft (non-saturated) scores, mixed key validity."""
+    64x64 / 128x128 (wc % 4 == 0: the LDS-staged kernel of round 4 -- 64x64 and 128x128 are the 256x256- and 512x512-input
+    sizes; 24x40 has wc = 20, 128x128 wc = 64 = the last width of the four-stage variant), 132x136 (wc = 68: three-stage
+    variant, hc = 66: ragged last patch row, rows that do not fit in registers: two-sweep statistics), 20x248 (wc = 124, the
+    widest the LDS-staged kernel takes).  The round-3 streaming kernel (SE_ATT_PTILDE_LDS=0) must agree to rounding: the two
+    kernels share the expression and the summation order.  Soft (non-saturated) scores, mixed key validity."""
     from oracle import sketchedit_oracle as O
     B, h, w = shape
     x = 0.004 * synth.uniform(5, "att96s.x%d" % h, (B, 96, h, w), -1, 1)
@@ -425,6 +429,10 @@ def test_op_attention_fused_streaming_pass(eng, shape, bf16, monkeypatch):
     monkeypatch.setenv("SE_ATT_FUSED", "1")
     monkeypatch.setenv("SE_ATT_FUSED_BF16", "1")
     fused = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
+    monkeypatch.setenv("SE_ATT_PTILDE_LDS", "0")
+    fused_r3 = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
+    monkeypatch.delenv("SE_ATT_PTILDE_LDS")
+    assert _md(fused, fused_r3) <= 1e-5 * float(fused.abs().max())      # (P~ differs by 1 ulp here and there: fma contraction)
     monkeypatch.setenv("SE_ATT_FUSED", "0")
     three = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
     if bf16:
