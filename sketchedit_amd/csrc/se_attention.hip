@@ -15,10 +15,6 @@
 
 #include <cstdlib>
 
-#ifndef SE_ATT_FUSED_BF16_DEFAULT
-#define SE_ATT_FUSED_BF16_DEFAULT false
-#endif
-
 namespace se {
 
 __global__ void att_prep_kernel(const AttParams p) {
@@ -509,7 +505,14 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
     const int row = rr + pr;
     const f32x4 v = *(const f32x4*)(T + row * TS + pc * 4);
     const int i = q0 + w * PT * 16 + row;
-    if (i < p.R && j < p.Rp) __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));      // streaming store (NT_STORE note at the top of this section)
+    if (i < p.R && j < p.Rp) {      // streaming store (NT_STORE note at the top of this section)
+      if (BF16 && p.e16) {          // E in fp16 (bf16 mode with the LDS-staged fused passes): 8 bytes per lane
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const h4 hv = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv), (u32x2*)((char*)p.E + (((size_t)b * p.R + i) * p.Rp + j) * 2));
+      } else __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));
+    }
   }
 }
 
@@ -1035,19 +1038,87 @@ __global__ __launch_bounds__(256) void att2_ptilde1_kernel(const AttParams p) {
 // (i, 0 .. 4) -- 14 instead of 36 bytes of LDS traffic per P value.
 // Expression, summation order and key test are those of att2_ptilde4_kernel (results agree to 1 ulp); a query that does not
 // exist carries -inf / 0, so the clamped or wrapped source rows it reads (finite) give exactly 0.
-// Needs wc % 4 == 0 (aligned 16-byte LDS reads at column shift wc) and wc <= 124 (ring of 256 >= C + wc + 4).
-// NIP = 1 KB DMA instructions per stage (the 36 x (C + wc + 4) / 4 sixteen-byte pieces, flat), a compile-time bound -- the
-// counted wait needs an immediate: 28 (wc <= 64: NS = 4 stages of 29 KB, 142 KB of LDS) or 36 (wc <= 124: NS = 3).
-template <bool BF16, int NIP, int NS>
+// Needs wc % 4 == 0 (aligned LDS reads at column shift wc) and wc <= 124 (ring of 256 >= C + wc + 4).
+// NIP = 1 KB DMA instructions per stage (the NR x ceil((C + wc + 4) / elements per 16 bytes) pieces, flat), a compile-time
+// bound -- the counted wait needs an immediate.  EH: E holds fp16 (bf16 mode, launch_attention_v2_t): half the bytes per stage.
+//
+// The stage machinery shared by att2_ptilde_lds_kernel (NR = 36 source rows on a 6-wide grid) and att2_stats_lds_kernel
+// (25 rows, 5 wide): producer wave `pid` of two issues instructions k = 2 m + pid of every stage; one barrier (`BARS` = 1) or
+// two per chunk on the consumer side.
+template <bool EH, int NIP, int NS, int NR, int GW, int BARS>
+DEVFN void lds_stage_producer(const AttParams& p, int b, int r00, int pid, int lane, int nchunks, char* smem) {
+  constexpr int C = 128, EB = EH ? 2 : 4, EPP = 16 / EB;
+  constexpr int SB = (NIP + 1) * 1024;
+  constexpr int NH = NIP / 2;                              // E instructions per producer wave and stage
+  static_assert(NIP % 2 == 0 && (NS - 2) * (NH + 1) <= 63, "vmcnt immediate");
+  const int NPR = (C + p.wc + 4 + EPP - 1) / EPP;          // 16-byte pieces per source row
+  const int NPT = NR * NPR;                                // E pieces of a stage (<= NIP * 64)
+  const se_i32x4 rsE = make_rsrc((const char*)p.E + (size_t)b * p.R * p.Rp * EB, (unsigned)p.R * (unsigned)p.Rp * (unsigned)EB);
+  unsigned goff[NH];                                       // piece -> byte offset inside the image's E
+  {
+    // row = pi / NPR without an integer division per piece: pieces advance by 128 per instruction of this wave
+    int pi = pid * 64 + lane;
+    int row = pi / NPR, cc = pi - row * NPR;
+    const int drow = 128 / NPR, dcc = 128 - drow * NPR;
+#pragma unroll
+    for (int m = 0; m < NH; ++m) {
+      const int i = row / GW, j = row - i * GW;
+      const int er = min(max(r00 + i * p.wc + j, 0), p.R - 1);
+      goff[m] = pi < NPT ? (unsigned)er * (unsigned)p.Rp * (unsigned)EB + (unsigned)cc * 16u : 0x80000000u;      // padding pieces: zeros
+      pi += 128; row += drow; cc += dcc;
+      if (cc >= NPR) { cc -= NPR; row += 1; }
+    }
+  }
+  const float* ktab = (lane < 32 ? p.kmul : p.kadd) + (size_t)b * p.Rp;
+  const int kl = 4 * (lane & 31);
+  const unsigned lds_e = lds_addr_of(smem);
+  auto issue = [&](int n) {
+    const unsigned base = lds_e + (unsigned)(n % NS) * SB + pid * 1024;
+    const unsigned s0b = (unsigned)(n * C) * (unsigned)EB;
+#pragma unroll
+    for (int m = 0; m < NH; ++m) bufdma16(__builtin_elementwise_add_sat(goff[m], s0b), rsE, base + m * 2048);
+    if (pid == 0) glds16(ktab + min(n * C + kl, p.Rp - 4), lds_e + (unsigned)(n % NS) * SB + NIP * 1024);      // [kmul 128][kadd 128]
+  };
+#pragma unroll
+  for (int n = 0; n < NS - 1; ++n)
+    if (n < nchunks) issue(n);
+  for (int n = 0; n < nchunks; ++n) {
+    const int y = min(NS - 2, nchunks - 1 - n);            // stages younger than n in flight
+    if (y >= NS - 2) {
+      if (pid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (NH + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NH) : "memory");
+    } else if (NS == 4 && y == 1) {
+      if (pid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // top: stage n is complete; the consumers are done with stage n - 1
+#ifndef PT_NODMA
+    if (n + NS - 1 < nchunks) issue(n + NS - 1);           // into the buffer of stage n - 1
+#endif
+    if (BARS == 2) __syncthreads();  // mid
+  }
+}
+// three consecutive elements c, c + 1, c + 2 (c even) of a staged source row
+template <bool EH>
+DEVFN void lds_row3(const char* row, int c, f32x2& v01, float& v2) {
+  if (EH) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = *(const h2*)(row + c * 2), bb = *(const h2*)(row + c * 2 + 4);
+    v01 = (f32x2){(float)a[0], (float)a[1]};
+    v2 = (float)bb[0];
+  } else {
+    v01 = *(const f32x2*)(row + c * 4);
+    v2 = *(const float*)(row + c * 4 + 8);
+  }
+}
+
+template <bool BF16, bool EH, int NIP, int NS>
 __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p, int npy, int npx) {
   constexpr int C = 128, NG = C / 4, RING = 256;
-  constexpr int ES = BF16 ? 2 : 4;
+  constexpr int ES = BF16 ? 2 : 4, EB = EH ? 2 : 4, EPP = 16 / EB;
   constexpr int SB = (NIP + 1) * 1024;                     // one stage: E pieces + (kmul, kadd) slice
-  constexpr int NH = NIP / 2;                              // E instructions per producer wave and stage
-  static_assert((NS - 2) * (NH + 1) <= 63, "vmcnt immediate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int WS = C + p.wc + 4, NPR = WS >> 2;              // staged columns per source row; 16-byte pieces per row
-  const int NPT = 36 * NPR;                                // E pieces of a stage (<= NIP * 64)
+  const int WSB = ((C + p.wc + 4 + EPP - 1) / EPP) * 16;   // bytes per staged source row
   float* Pr = (float*)(smem + NS * SB);                    // [25][RING]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1057,54 +1128,8 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
   const int ry0 = 4 * py, rx0 = 4 * px;
   const int nchunks = (p.Rp + C - 1) / C;
 
-  if (w >= 8) {
-    // ---------------- producer waves: instruction k = 2 m + pid of a stage covers pieces k * 64 .. + 63
-    const int pid = w - 8;
-    const int r00 = (ry0 - 1) * p.wc + rx0 - 1;            // source row (i', j') = r00 + i' wc + j' (linear, as r + dl in att2_ptilde4_kernel)
-    const se_i32x4 rsE = make_rsrc(p.E + (size_t)b * p.R * p.Rp, (unsigned)p.R * (unsigned)p.Rp * 4u);
-    unsigned goff[NH];                                     // piece -> byte offset inside the image's E
-    {
-      // row = pi / NPR without an integer division per piece: pieces advance by 128 per instruction of this wave
-      int pi = pid * 64 + lane;
-      int row = pi / NPR, cc = pi - row * NPR;
-      const int drow = 128 / NPR, dcc = 128 - drow * NPR;
-#pragma unroll
-      for (int m = 0; m < NH; ++m) {
-        const int i = row / 6, j = row - i * 6;
-        const int er = min(max(r00 + i * p.wc + j, 0), p.R - 1);
-        goff[m] = pi < NPT ? (unsigned)er * (unsigned)p.Rp * 4u + (unsigned)cc * 16u : 0x80000000u;      // padding pieces: zeros
-        pi += 128; row += drow; cc += dcc;
-        if (cc >= NPR) { cc -= NPR; row += 1; }
-      }
-    }
-    const float* ktab = (lane < 32 ? p.kmul : p.kadd) + (size_t)b * p.Rp;
-    const int kl = 4 * (lane & 31);
-    const unsigned lds_e = lds_addr_of(smem);
-    auto issue = [&](int n) {
-      const unsigned base = lds_e + (unsigned)(n % NS) * SB + pid * 1024;
-      const unsigned s0b = (unsigned)(n * C) * 4u;
-#pragma unroll
-      for (int m = 0; m < NH; ++m) bufdma16(__builtin_elementwise_add_sat(goff[m], s0b), rsE, base + m * 2048);
-      if (pid == 0) glds16(ktab + min(n * C + kl, p.Rp - 4), lds_e + (unsigned)(n % NS) * SB + NIP * 1024);      // [kmul 128][kadd 128]
-    };
-#pragma unroll
-    for (int n = 0; n < NS - 1; ++n)
-      if (n < nchunks) issue(n);
-    for (int n = 0; n < nchunks; ++n) {
-      const int y = min(NS - 2, nchunks - 1 - n);          // stages younger than n in flight
-      if (y >= NS - 2) {
-        if (pid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (NH + 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NH) : "memory");
-      } else if (NS == 4 && y == 1) {
-        if (pid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
-      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();               // top: stage n is complete (consumers: done with phase C of n - 1)
-#ifndef PT_NODMA
-      if (n + NS - 1 < nchunks) issue(n + NS - 1);         // into the buffer of stage n - 1 (phase B of n - 1 ended before its mid barrier)
-#endif
-      __syncthreads();               // mid
-    }
+  if (w >= 8) {      // source row (i', j') = r00 + i' wc + j' (linear, as r + dl in att2_ptilde4_kernel)
+    lds_stage_producer<EH, NIP, NS, 36, 6, 2>(p, b, (ry0 - 1) * p.wc + rx0 - 1, w - 8, lane, nchunks, smem);
     return;
   }
 
@@ -1123,7 +1148,7 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
   }
   for (int n = 0; n < nchunks; ++n) {
     const int s0 = n * C;
-    const float* Eb = (const float*)(smem + (n % NS) * SB);
+    const char* Eb = smem + (n % NS) * SB;
     const float* Kt = (const float*)(smem + (n % NS) * SB + NIP * 1024);
     __syncthreads();                 // top
     // ---- phase B
@@ -1134,10 +1159,8 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
       float x0[6], x1[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const float* e0 = Eb + (w * 6 + j) * WS + c;           // (i, j')      columns c, c + 1 | c + 2
-        const float* e1 = e0 + 6 * WS + p.wc;                  // (i + 1, j')  columns c + wc, c + wc + 1 | c + wc + 2
-        r0[j] = *(const f32x2*)e0; x0[j] = e0[2];
-        r1[j] = *(const f32x2*)e1; x1[j] = e1[2];
+        lds_row3<EH>(Eb + (w * 6 + j) * WSB, c, r0[j], x0[j]);                  // (i, j')      columns c, c + 1 | c + 2
+        lds_row3<EH>(Eb + (w * 6 + 6 + j) * WSB, c + p.wc, r1[j], x1[j]);       // (i + 1, j')  columns c + wc, c + wc + 1 | c + wc + 2
       }
       const f32x2 mu = *(const f32x2*)(Kt + c), ad = *(const f32x2*)(Kt + C + c);
 #pragma unroll
@@ -1176,16 +1199,76 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
         const int r = (ry0 + a) * p.wc + rx0 + bx;
         char* out = (char*)p.P + (((size_t)b * p.R + r) * p.Rp + s) * ES;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#ifdef PT_NOSTORE
-        if (acc[0] == 12345.f)
-#endif
-        {
-          if (BF16) __builtin_nontemporal_store((u32x2){pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])}, (u32x2*)out);
-          else __builtin_nontemporal_store(acc, (f32x4*)out);
-        }
+        if (BF16) __builtin_nontemporal_store((u32x2){pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])}, (u32x2*)out);
+        else __builtin_nontemporal_store(acc, (f32x4*)out);
       }
     }
 #endif
+  }
+}
+
+// att2_stats_lds_kernel: the statistics pass on the same stage machinery.  att2_stats_kernel reads every row of E for each of
+// the four queries it feeds (through L2: 4 x the bytes of E); here a workgroup owns a 4 x 4 patch of QUERIES, stages the
+// 5 x 5 source rows (25 / 16 = 1.6 x) and keeps an online (maximum, sum) per (query, lane):
+//   m' = max(m, t0, t1), l = l exp2(m - m') + exp2(t0 - m') + exp2(t1 - m'),    t = fma(sumE, kmul, kadd)  (-inf: not a key)
+// with m starting at a finite -1e30 (exp2(-inf - m') = 0, never inf - inf).  The softmax is invariant to the shift as long as
+// l is formed with the same m, so the pair only has to be CONSISTENT; it differs from att2_stats_kernel's (row maximum, one
+// sum in column order) in rounding.  Four consumer waves (wave = query row i, lane = column pair) + two producers, one
+// barrier per chunk; 3 stages, two workgroups per CU.
+template <bool EH, int NIP, int NS>
+__global__ __launch_bounds__(384) void att2_stats_lds_kernel(const AttParams p, int npy, int npx) {
+  constexpr int C = 128;
+  constexpr int EB = EH ? 2 : 4, EPP = 16 / EB;
+  constexpr int SB = (NIP + 1) * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int WSB = ((C + p.wc + 4 + EPP - 1) / EPP) * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lb = xcd_tile(blockIdx.x, gridDim.x);
+  const int b = lb / (npy * npx), rem = lb - b * (npy * npx);
+  const int py = rem / npx, px = rem - py * npx;
+  const int qy0 = 4 * py, qx0 = 4 * px;
+  const int nchunks = (p.Rp + C - 1) / C;
+  if (w >= 4) {
+    lds_stage_producer<EH, NIP, NS, 25, 5, 1>(p, b, qy0 * p.wc + qx0, w - 4, lane, nchunks, smem);
+    return;
+  }
+  float m_[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, l_[4] = {0.f, 0.f, 0.f, 0.f};      // online (max, sum) of queries (w, 0..3), this lane's columns
+  for (int n = 0; n < nchunks; ++n) {
+    const char* Eb = smem + (n % NS) * SB;
+    const float* Kt = (const float*)(smem + (n % NS) * SB + NIP * 1024);
+    __syncthreads();                 // top
+    const int c = 2 * lane;
+    f32x2 r0[5], r1[5];
+    float x0[5], x1[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      lds_row3<EH>(Eb + (w * 5 + j) * WSB, c, r0[j], x0[j]);
+      lds_row3<EH>(Eb + (w * 5 + 5 + j) * WSB, c + p.wc, r1[j], x1[j]);
+    }
+    const f32x2 mu = *(const f32x2*)(Kt + c), ad = *(const f32x2*)(Kt + C + c);
+    const bool live = n * C + c < p.Rp;                    // (columns beyond Rp: the table slice was clamped, skip)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 sum = ((r0[j] + (f32x2){r0[j + 1][1], x0[j + 1]}) + r1[j]) + (f32x2){r1[j + 1][1], x1[j + 1]};
+      f32x2 t = sum * mu + ad;
+      if (!live) t = (f32x2){-INFINITY, -INFINITY};
+      const float mn = fmaxf(m_[j], fmaxf(t[0], t[1]));
+      l_[j] = l_[j] * __builtin_amdgcn_exp2f(m_[j] - mn) + (__builtin_amdgcn_exp2f(t[0] - mn) + __builtin_amdgcn_exp2f(t[1] - mn));
+      m_[j] = mn;
+    }
+  }
+  // lanes -> one (m, l) per query
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float m = m_[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float l = l_[j] * __builtin_amdgcn_exp2f(m_[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    const int qy = qy0 + w, qx = qx0 + j;
+    if (lane == 0 && qy < p.hs && qx < p.ws) *(float2*)(p.stats + ((size_t)b * p.R + qy * p.wc + qx) * 2) = make_float2(m, 1.f / l);
   }
 }
 
@@ -1288,16 +1371,19 @@ __global__ void att2_similar_kernel(const AttParams p) {
   p.similar[idx] = BF16 ? bf16_lo(((const unsigned short*)p.P)[at]) : p.P[at];
 }
 
-// Which form runs (measured on MI355X; same-box A/B runs of round 4, tools/_build/att_ab.sh):
-//   256x256 inputs (R = 1024), 32 images:  three-pass 65 + 71 us | fused, round-3 kernels 44 + 89 us | fused, LDS-staged 44 + 81 us
-//   512x512 inputs (R = 4096),  8 images:  three-pass 272 + 269 us | round-3 fused 183 + 410 us     | LDS-staged 184 + 263 us
+// Which form runs (measured on MI355X; same-box A/B runs of round 4, tools/_build/att_ab.sh; statistics + P~ pass):
+//   256x256 inputs (R = 1024), 32 images:  three-pass 65 + 71 us | fused, round-3 kernels 44 + 89 us | fused, LDS-staged P~ 44 + 81 us
+//   512x512 inputs (R = 4096),  8 images:  three-pass 272 + 269 us | round-3 fused 183 + 410 us | LDS-staged 135 + 263 us
 //       (the round-3 streaming kernel was bound by the L2 -> L1 traffic of its nine source rows per output row; the LDS-staged
 //       kernel reads and writes HBM at 4.1 TB/s: 1.07 GB in 263 us)
-//   bf16 (512x512, 16 images): three-pass 452 + 275 us | LDS-staged fused 349 + 457 us: P is bf16 there, so the fused form saves
-//       no bytes (E, fp32, is read twice instead of E + P once each) -> three-pass.
-// fp32 default: fused wherever the LDS-staged kernel applies (wc % 4 == 0, wc <= 124) and for R <= 1024.  SE_ATT_FUSED=0 / 1
-// forces the three-pass / fused form; SE_ATT_FUSED_BF16=1 extends the choice to bf16 mode; SE_ATT_PTILDE_LDS=0 keeps the
-// round-3 streaming kernel inside the fused form.  (Read per call, not cached: the tests switch forms inside one process.)
+//   bf16 (512x512, 16 images): three-pass 443 + 272 us | LDS-staged, E fp32 245 + 463 us | LDS-staged, E fp16 161 + 386 us
+//       (P is bf16 there, so with fp32 E the fused form saves no bytes; with E in fp16 -- written by the E GEMM, converted by
+//       the two LDS-staged kernels, the only readers -- the step goes 7.07 -> 6.87 ms)
+// Default: fused wherever the LDS-staged kernels apply (wc % 4 == 0, wc <= 124), in fp32 also for R <= 1024 (round-3 kernels).
+// SE_ATT_FUSED=0 / 1 forces the three-pass / fused form (in bf16 mode together with SE_ATT_FUSED_BF16=1); SE_ATT_FUSED_BF16=0
+// keeps bf16 mode on the three-pass form; SE_ATT_PTILDE_LDS=0 keeps the round-3 streaming kernels inside the fused form;
+// SE_ATT_STATS_LDS=0 the round-3 statistics kernel; SE_ATT_E16=0 fp32 E in bf16 mode.  (Read per call, not cached: the tests
+// switch forms inside one process.)
 static bool att_lds_form(int wc) {
   const char* e = getenv("SE_ATT_PTILDE_LDS");
   return wc % 4 == 0 && wc <= 124 && !(e && atoi(e) == 0);
@@ -1306,8 +1392,11 @@ static bool att_fused(bool bf16, int Rp, int wc) {
   const char* e1 = getenv("SE_ATT_FUSED");
   const char* e2 = getenv("SE_ATT_FUSED_BF16");
   const int f32mode = e1 ? (atoi(e1) != 0 ? 1 : 0) : -1;
-  const bool bfon = e2 ? atoi(e2) != 0 : SE_ATT_FUSED_BF16_DEFAULT;
-  if (bf16 && !bfon) return false;
+  if (bf16) {
+    if (e2 && atoi(e2) == 0) return false;
+    if (e2) return f32mode < 0 ? att_lds_form(wc) : f32mode == 1;      // (explicitly enabled: SE_ATT_FUSED decides, as in fp32)
+    return f32mode != 0 && att_lds_form(wc);
+  }
   return f32mode < 0 ? (Rp <= 1024 || att_lds_form(wc)) : f32mode == 1;
 }
 
@@ -1316,6 +1405,10 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
   AttParams p = p0;
   const bool fused = att_fused(BF16, p.Rp, p.wc) && !p.similar && p.stats;      // `similar_out` is P itself: three-pass form
   p.Pt = fused ? p.P : p.E;
+  // SE_ATT_STATS_LDS=0: att2_stats_kernel instead of the LDS-staged statistics pass.  SE_ATT_E16=0: E stays fp32 in bf16 mode
+  // (fp16 E needs both LDS-staged kernels: they are the only readers that convert).
+  const bool stats_lds = !(getenv("SE_ATT_STATS_LDS") && atoi(getenv("SE_ATT_STATS_LDS")) == 0);
+  p.e16 = (BF16 && fused && att_lds_form(p.wc) && stats_lds && !(getenv("SE_ATT_E16") && atoi(getenv("SE_ATT_E16")) == 0)) ? 1 : 0;
   {
     const long n = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);
     // Preconditions of the fused streaming pass: its column shifts read up to wc + 8 floats in front of / behind
@@ -1352,11 +1445,32 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     }
   }
   if (fused) {
+    const bool lds_form = att_lds_form(p.wc);
+    // the two LDS-staged kernels: <E in fp16, DMA instructions per stage> by width (compile-time: the producers' counted waits)
+#define SE_LAUNCH_STATS_LDS(EH, NIP)                                                                                   \
+  do {                                                                                                                 \
+    constexpr int lds = 3 * ((NIP) + 1) * 1024;                                                                        \
+    hipError_t e = ensure_max_lds((const void*)att2_stats_lds_kernel<EH, NIP, 3>, lds);                                \
+    if (e != hipSuccess) return e;                                                                                     \
+    const int npy = (p.hs + 3) / 4, npx = (p.ws + 3) / 4;                                                              \
+    hipLaunchKernelGGL((att2_stats_lds_kernel<EH, NIP, 3>), dim3((unsigned)(p.B * npy * npx)), dim3(384), lds, st, p, npy, npx); \
+  } while (0)
+#define SE_LAUNCH_PTILDE_LDS(EH, NIP, NS)                                                                              \
+  do {                                                                                                                 \
+    constexpr int lds = (NS) * ((NIP) + 1) * 1024 + 25 * 256 * 4;                                                      \
+    hipError_t e = ensure_max_lds((const void*)att2_ptilde_lds_kernel<BF16, EH, NIP, NS>, lds);                        \
+    if (e != hipSuccess) return e;                                                                                     \
+    const int npy = (p.hc + 3) / 4, npx = p.wc / 4;                                                                    \
+    hipLaunchKernelGGL((att2_ptilde_lds_kernel<BF16, EH, NIP, NS>), dim3((unsigned)(p.B * npy * npx)), dim3(640), lds, st, p, npy, npx); \
+  } while (0)
     {
       const long rows = tile_order_count(p.B, p.hs, p.ws);
       ProfScope ps_(st, PL_ATT_SOFTMAX);
       const dim3 grid((unsigned)((rows + 3) / 4));
-      if (p.Rp <= 64 * 16) hipLaunchKernelGGL((att2_stats_kernel<16, BF16>), grid, dim3(256), 0, st, p);
+      if (lds_form && stats_lds && (p.e16 || p.Rp > 1024)) {      // (R <= 1024: the register kernel is as fast, 44 vs 46 us)
+        if (p.e16) { if (p.wc <= 64) SE_LAUNCH_STATS_LDS(true, 10); else SE_LAUNCH_STATS_LDS(true, 14); }
+        else { if (p.wc <= 64) SE_LAUNCH_STATS_LDS(false, 20); else SE_LAUNCH_STATS_LDS(false, 26); }
+      } else if (p.Rp <= 64 * 16) hipLaunchKernelGGL((att2_stats_kernel<16, BF16>), grid, dim3(256), 0, st, p);
       else if (p.Rp <= 64 * 64) hipLaunchKernelGGL((att2_stats_kernel<64, BF16>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((att2_stats_kernel<0, BF16>), grid, dim3(256), 0, st, p);
     }
@@ -1364,24 +1478,20 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       const long rows = tile_order_count(p.B, p.hc, p.wc);
       ProfScope ps_(st, PL_ATT_BOXSUM);
       const dim3 grid((unsigned)((rows + 3) / 4));
-      const bool lds_form = att_lds_form(p.wc);
       if (lds_form) {
-        const int npy = (p.hc + 3) / 4, npx = p.wc / 4;
-        const dim3 g((unsigned)(p.B * npy * npx));
-        if (p.wc <= 64) {
-          constexpr int lds = 4 * 29 * 1024 + 25 * 256 * 4;
-          hipError_t e = ensure_max_lds((const void*)att2_ptilde_lds_kernel<BF16, 28, 4>, lds);
-          if (e != hipSuccess) return e;
-          hipLaunchKernelGGL((att2_ptilde_lds_kernel<BF16, 28, 4>), g, dim3(640), lds, st, p, npy, npx);
-        } else {
-          constexpr int lds = 3 * 37 * 1024 + 25 * 256 * 4;
-          hipError_t e = ensure_max_lds((const void*)att2_ptilde_lds_kernel<BF16, 36, 3>, lds);
-          if (e != hipSuccess) return e;
-          hipLaunchKernelGGL((att2_ptilde_lds_kernel<BF16, 36, 3>), g, dim3(640), lds, st, p, npy, npx);
+        bool done = false;
+        if constexpr (BF16) {
+          if (p.e16) {
+            if (p.wc <= 64) SE_LAUNCH_PTILDE_LDS(true, 16, 3); else SE_LAUNCH_PTILDE_LDS(true, 18, 3);      // 3 stages: 77 / 83 KB, two workgroups per CU
+            done = true;
+          }
         }
+        if (!done) { if (p.wc <= 64) SE_LAUNCH_PTILDE_LDS(false, 28, 4); else SE_LAUNCH_PTILDE_LDS(false, 36, 3); }
       } else if (p.wc % 4 == 0) hipLaunchKernelGGL((att2_ptilde4_kernel<BF16>), dim3((unsigned)((rows + 7) / 8)), dim3(512), 0, st, p);
       else hipLaunchKernelGGL((att2_ptilde1_kernel<BF16>), grid, dim3(256), 0, st, p);
     }
+#undef SE_LAUNCH_STATS_LDS
+#undef SE_LAUNCH_PTILDE_LDS
   } else {
     {
       const long rows = tile_order_count(p.B, p.hs, p.ws);

@@ -285,6 +285,7 @@ struct AttParams {
   float* validR;       // [B][Rp]    workspace: key validity in class-grid indexing: 1 / 0, -1 where the position is not a key
   float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
   int bf16;            // x, xn, xT, P~ (in the E buffer) and out hold bf16; Rp is then a multiple of 64
+  int e16;             // set by the launcher: E holds fp16 (bf16 mode, LDS-staged fused passes)
 };
 hipError_t launch_attention(const AttParams& p, hipStream_t st);    // p.E != null: space-to-depth form, else the patch form
 bool attention_v2_enabled();

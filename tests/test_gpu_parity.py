@@ -420,7 +420,9 @@ def test_op_attention_fused_streaming_pass(eng, shape, bf16, monkeypatch):
     sizes; 24x40 has wc = 20, 128x128 wc = 64 = the last width of the four-stage variant), 132x136 (wc = 68: three-stage
     variant, hc = 66: ragged last patch row, rows that do not fit in registers: two-sweep statistics), 20x248 (wc = 124, the
     widest the LDS-staged kernel takes).  The round-3 streaming kernel (SE_ATT_PTILDE_LDS=0) must agree to rounding: the two
-    kernels share the expression and the summation order.  Soft (non-saturated) scores, mixed key validity."""
+    kernels share the expression and the summation order; so must the round-3 statistics kernel (SE_ATT_STATS_LDS=0; the
+    LDS-staged one keeps an online maximum / sum per lane) and, in bf16 mode, E kept in fp32 (SE_ATT_E16=0; fp16 by default
+    there).  Soft (non-saturated) scores, mixed key validity."""
     from oracle import sketchedit_oracle as O
     B, h, w = shape
     x = 0.004 * synth.uniform(5, "att96s.x%d" % h, (B, 96, h, w), -1, 1)
@@ -432,18 +434,29 @@ def test_op_attention_fused_streaming_pass(eng, shape, bf16, monkeypatch):
     monkeypatch.setenv("SE_ATT_PTILDE_LDS", "0")
     fused_r3 = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
     monkeypatch.delenv("SE_ATT_PTILDE_LDS")
-    assert _md(fused, fused_r3) <= 1e-5 * float(fused.abs().max())      # (P~ differs by 1 ulp here and there: fma contraction)
+    if not bf16:
+        assert _md(fused, fused_r3) <= 1e-5 * float(fused.abs().max())      # (P~ differs by 1 ulp here and there: fma contraction)
+    monkeypatch.setenv("SE_ATT_E16", "0")
+    fused_e32 = eng.attention(_cuda(x), _cuda(full), bf16=bf16)               # bf16 mode: E in fp32 instead of fp16
+    monkeypatch.delenv("SE_ATT_E16")
+    monkeypatch.setenv("SE_ATT_STATS_LDS", "0")
+    fused_s3 = eng.attention(_cuda(x), _cuda(full), bf16=bf16)                # round-3 statistics kernel (and fp32 E)
+    monkeypatch.delenv("SE_ATT_STATS_LDS")
     monkeypatch.setenv("SE_ATT_FUSED", "0")
     three = eng.attention(_cuda(x), _cuda(full), bf16=bf16)
     if bf16:
         ro, _ = O.contextual_attention(torch.from_numpy(x).to(torch.bfloat16).float(), torch.from_numpy(full), torch.bfloat16)
         tol = 2.0 ** -7 * float(ro.abs().max())
         assert _md(fused, ro) < tol and _md(fused, three) < tol
+        for other in (fused_r3, fused_e32, fused_s3):
+            assert _md(other, ro) < tol and _md(fused, other) < tol
     else:
         ro, _ = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
         tol = (1e-5 if h < 100 else 1e-4) * float(ro.abs().max())
         assert _md(fused, ro) < tol
         assert _md(fused, three) < 1e-5 * float(ro.abs().max())       # v_exp_f32 vs expf: ~1e-7 relative per probability
+        assert _md(fused, fused_e32) == 0.0                           # (the switch only exists in bf16 mode)
+        assert _md(fused_s3, ro) < tol and _md(fused, fused_s3) < 1e-5 * float(ro.abs().max())
 
 
 def test_op_attention_vs_oracle(eng):
