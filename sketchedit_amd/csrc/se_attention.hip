@@ -1036,6 +1036,9 @@ __global__ __launch_bounds__(256) void att2_ptilde1_kernel(const AttParams p) {
 // (same box): DMA + barriers alone 174 us = 3.1 TB/s of E -- latency x bytes in flight, not HBM -- phase B +36, phase C +51.
 // A phase-B task is (query ROW i, column pair): the 12 source rows (i .. i+1, 0 .. 5) are read once for the five queries
 // (i, 0 .. 4) -- 14 instead of 36 bytes of LDS traffic per P value.
+// Tried and not faster: phases B and C of consecutive chunks side by side (15 waves: 5 on phase B of chunk k, 8 on phase C of
+// chunk k - 1, 2 producers; one barrier per chunk, a 512-column ring, 3 stages = 138 KB): 272 vs 266 us at 512x512 B=8 fp32,
+// 556 vs 485 us at 512x512 B=16 bf16 with fp32 E (same box) -- one stage fewer in flight costs more than the overlap gains.
 // Expression, summation order and key test are those of att2_ptilde4_kernel (results agree to 1 ulp); a query that does not
 // exist carries -inf / 0, so the clamped or wrapped source rows it reads (finite) give exactly 0.
 // Needs wc % 4 == 0 (aligned LDS reads at column shift wc) and wc <= 124 (ring of 256 >= C + wc + 4).
