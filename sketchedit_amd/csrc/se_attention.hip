@@ -58,8 +58,19 @@ __global__ __launch_bounds__(256) void att_score_kernel(const AttParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z;
-  const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
+  int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+  if (p.sym) {      // 1-D grid over the computed tiles only: (image, t), t enumerates (key tile by, query tile bx <= by / 4), bx fastest
+    static_assert(PIX == 4 * NP, "tile enumeration");
+    b = blockIdx.x / p.symT;
+    const int t = blockIdx.x - b * p.symT;
+    int g = (int)((sqrtf(1.f + 2.f * (float)t) - 1.f) * 0.5f);      // group g = by / 4 holds 4 (g + 1) tiles, 2 g (g + 1) before it
+    while (2 * (g + 1) * (g + 2) <= t) ++g;
+    while (2 * g * (g + 1) > t) --g;
+    const int rem = t - 2 * g * (g + 1), yy = rem / (g + 1);
+    by = 4 * g + yy;
+    bx = rem - yy * (g + 1);
+  }
+  const int q0 = bx * PIX, k0 = by * NP;
   // byte offset of the patch origin of a query / key row inside THIS image, or an out-of-range offset: both
   // operands are staged through buffer resources (hardware zero fill, one VALU add per granule; se_gconv.hip)
   auto origin = [&](int i) -> unsigned {
@@ -430,8 +441,24 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // (an image-major 1-D grid with one contiguous range per XCD was measured: no gain in fp32, 0.47 -> 0.67 ms in bf16
   // where the kernel is bound by the 1 GB of E it writes -- the plain 3-D grid spreads those writes over all XCDs)
-  const int b = blockIdx.z;
-  const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
+  int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+  if (p.sym) {      // 1-D grid over the computed tiles only: (image, t), t enumerates (key tile by, query tile bx <= by / 4), bx fastest
+    static_assert(PIX == 4 * NP, "tile enumeration");
+    b = blockIdx.x / p.symT;
+    const int t = blockIdx.x - b * p.symT;
+    int g = (int)((sqrtf(1.f + 2.f * (float)t) - 1.f) * 0.5f);      // group g = by / 4 holds 4 (g + 1) tiles, 2 g (g + 1) before it
+    while (2 * (g + 1) * (g + 2) <= t) ++g;
+    while (2 * g * (g + 1) > t) --g;
+    const int rem = t - 2 * g * (g + 1), yy = rem / (g + 1);
+    by = 4 * g + yy;
+    bx = rem - yy * (g + 1);
+  }
+  const int q0 = bx * PIX, k0 = by * NP;
+  // E is symmetric: E[r][s] = sum_c x[r][c] x[s][c] rn[c] (the key normalisation is per CHANNEL, splitcam.py:40), so with
+  // p.sym (fp32 mode) only the tiles with k0 >= q0 are computed: a tile right of its diagonal block (k0 >= q0 + PIX) also
+  // stores its transpose, which is exactly the set of tiles skipped here (the mirrored value is sum x[s] fl(x[r] rn) instead of
+  // sum x[r] fl(x[s] rn): two roundings per term either way).  53 % of the tiles at R = 4096; the grid holds only those (a 3-D
+  // grid whose left-of-diagonal workgroups returned at once measured NO gain: 0.786 -> 0.805 ms).
   // byte offset of the 2x2 block origin of a row inside THIS image, or an out-of-range offset (hardware zero fill)
   auto origin = [&](int i) -> unsigned {
     if (i >= p.R) return 0x80000000u;
@@ -512,6 +539,21 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
         const h4 hv = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv), (u32x2*)((char*)p.E + (((size_t)b * p.R + i) * p.Rp + j) * 2));
       } else __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));
+    }
+  }
+  if (!BF16 && p.sym == 1 && k0 >= q0 + PIX) {
+    // the transposed tile: row = key k0 + kk, 16 lanes write its PT*16 queries (of this wave) as 16-byte pieces
+    constexpr int PPM = PT * 4;                      // pieces per mirrored row
+    constexpr int RPM = 64 / PPM;                    // mirrored rows per store instruction
+    const int mc = lane % PPM, mr = lane / PPM;
+    const int qcol = q0 + w * PT * 16 + mc * 4;
+#pragma unroll
+    for (int kk0 = 0; kk0 < NT * 16; kk0 += RPM) {
+      const int kk = kk0 + mr;
+      const float* t = T + (mc * 4) * TS + kk;
+      const f32x4 v = (f32x4){t[0], t[TS], t[2 * TS], t[3 * TS]};
+      const int srow = k0 + kk;
+      if (srow < p.R && qcol < p.Rp) __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + srow) * p.Rp + qcol));
     }
   }
 }
@@ -1410,6 +1452,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
   p.Pt = fused ? p.P : p.E;
   // SE_ATT_STATS_LDS=0: att2_stats_kernel instead of the LDS-staged statistics pass.  SE_ATT_E16=0: E stays fp32 in bf16 mode
   // (fp16 E needs both LDS-staged kernels: they are the only readers that convert).
+  p.sym = BF16 ? 0 : (getenv("SE_ATT_SYM") ? atoi(getenv("SE_ATT_SYM")) : 1);      // SE_ATT_SYM=0: every tile of E computed (2: debug, no mirror store)
   const bool stats_lds = !(getenv("SE_ATT_STATS_LDS") && atoi(getenv("SE_ATT_STATS_LDS")) == 0);
   p.e16 = (BF16 && fused && att_lds_form(p.wc) && stats_lds && !(getenv("SE_ATT_E16") && atoi(getenv("SE_ATT_E16")) == 0)) ? 1 : 0;
   {
@@ -1433,6 +1476,11 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
       if (e != hipSuccess) return e;
       dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+      if (p.sym) {
+        const int ny = grid.y, G = ny / 4;
+        p.symT = 2 * G * (G + 1) + (ny - 4 * G) * (G + 1);
+        grid = dim3((unsigned)(p.symT * p.B));
+      }
       set_launch_grid((long)grid.x * grid.y * grid.z);
       ProfScope ps_(st, PL_ATT_SCORE);
       hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
@@ -1442,6 +1490,11 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
       if (e != hipSuccess) return e;
       dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+      if (p.sym) {
+        const int ny = grid.y, G = ny / 4;
+        p.symT = 2 * G * (G + 1) + (ny - 4 * G) * (G + 1);
+        grid = dim3((unsigned)(p.symT * p.B));
+      }
       set_launch_grid((long)grid.x * grid.y * grid.z);
       ProfScope ps_(st, PL_ATT_SCORE);
       hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);

@@ -286,6 +286,8 @@ struct AttParams {
   float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
   int bf16;            // x, xn, xT, P~ (in the E buffer) and out hold bf16; Rp is then a multiple of 64
   int e16;             // set by the launcher: E holds fp16 (bf16 mode, LDS-staged fused passes)
+  int sym;             // set by the launcher: att2_pair_kernel computes the tiles on / right of the diagonal and mirrors them (fp32)
+  int symT;            //   ... computed tiles per image (1-D grid)
 };
 hipError_t launch_attention(const AttParams& p, hipStream_t st);    // p.E != null: space-to-depth form, else the patch form
 bool attention_v2_enabled();

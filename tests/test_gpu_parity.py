@@ -459,6 +459,28 @@ def test_op_attention_fused_streaming_pass(eng, shape, bf16, monkeypatch):
         assert _md(fused_s3, ro) < tol and _md(fused, fused_s3) < 1e-5 * float(ro.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16), (2, 24, 40), (1, 72, 64), (1, 132, 136)], ids=lambda s: "%dx%dx%d" % s)
+def test_op_attention_symmetric_score_tiles(eng, shape, monkeypatch):
+    """E[r][s] = sum_c x[r][c] x[s][c] rn[c] is symmetric, and in fp32 mode att2_pair_kernel computes only the tiles on / right
+    of the diagonal and stores their transposes (se_attention.hip).  With soft scores (every key matters: softmax far from
+    one-hot) the probabilities must match the oracle and the all-tiles form (SE_ATT_SYM=0) -- a tile missing from the
+    enumeration, or a transposed store that lands in the wrong place, changes whole 64 x 256 blocks of E.  16x16: one tile;
+    24x40 (R = 240): the 128 x 32 tile shape; 72x64 (R = 1152: 5 x 18 tiles, ragged last query tile); 132x136 (R = 4488)."""
+    from oracle import sketchedit_oracle as O
+    B, h, w = shape
+    x = 0.004 * synth.uniform(5, "att96y.x%d" % h, (B, 96, h, w), -1, 1)
+    full = (synth.uniform(5, "att96y.m%d" % h, (B, 1, 4 * h, 4 * w), 0, 1) < 0.5).astype(np.float32)
+    out, sim = eng.attention(_cuda(x), _cuda(full), want_similar=True)
+    monkeypatch.setenv("SE_ATT_SYM", "0")
+    out0, sim0 = eng.attention(_cuda(x), _cuda(full), want_similar=True)
+    ro, rp = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
+    if h < 100:
+        assert float(rp.max()) < 0.5                                      # far from one-hot
+    assert _md(sim, rp) < 2e-6 and _md(sim0, rp) < 2e-6 and _md(sim, sim0) < 2e-6
+    tol = (1e-5 if h < 100 else 1e-4) * float(ro.abs().max())
+    assert _md(out, ro) < tol and _md(out, out0) < tol
+
+
 def test_op_attention_vs_oracle(eng):
     from oracle import sketchedit_oracle as O
     x = synth.uniform(5, "att96.x", (2, 96, 12, 16), -1, 1)
