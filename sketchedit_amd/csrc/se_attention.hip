@@ -59,16 +59,31 @@ __global__ __launch_bounds__(256) void att_score_kernel(const AttParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (p.sym) {      // 1-D grid over the computed tiles only: (image, t), t enumerates (key tile by, query tile bx <= by / 4), bx fastest
+  if (p.sym) {
+    // 1-D grid over the computed tiles only (bx <= by / 4), every XCD a contiguous range (xcd_tile).  Order: image, PANEL of 16
+    // key tiles (by = 16 pn .. + 15), query tile bx, key tile -- the 64 workgroups resident on an XCD are 4 query tiles x the 16
+    // key tiles of one panel: 3.1 MB of operands in its 4 MB L2 for 64 tiles (49 KB per tile instead of 491), and the panel's
+    // keys stay there for every bx.  (by-major order without the XCD remap: 967 MB fetched per launch at R = 4096 B=8 for
+    // 100 MB of operands, and the kernel is then partly bound by that.)  Panel pn holds 64 pn full tiles + the 16 + 12 + 8 + 4
+    // of its diagonal blocks; 32 pn^2 + 8 pn tiles before it.
     static_assert(PIX == 4 * NP, "tile enumeration");
-    b = blockIdx.x / p.symT;
-    const int t = blockIdx.x - b * p.symT;
-    int g = (int)((sqrtf(1.f + 2.f * (float)t) - 1.f) * 0.5f);      // group g = by / 4 holds 4 (g + 1) tiles, 2 g (g + 1) before it
-    while (2 * (g + 1) * (g + 2) <= t) ++g;
-    while (2 * g * (g + 1) > t) --g;
-    const int rem = t - 2 * g * (g + 1), yy = rem / (g + 1);
-    by = 4 * g + yy;
-    bx = rem - yy * (g + 1);
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    b = lb / p.symT;
+    const int t = lb - b * p.symT;
+    int pn = (int)((sqrtf(64.f + 128.f * (float)t) - 8.f) * (1.f / 64.f));
+    while (32 * (pn + 1) * (pn + 1) + 8 * (pn + 1) <= t) ++pn;
+    while (32 * pn * pn + 8 * pn > t) --pn;
+    const int u = t - (32 * pn * pn + 8 * pn);
+    if (u < 64 * pn) {
+      bx = u >> 4;
+      by = 16 * pn + (u & 15);
+    } else {
+      const int v = u - 64 * pn;
+      const int j = v < 16 ? 0 : (v < 28 ? 1 : (v < 36 ? 2 : 3));
+      bx = 4 * pn + j;
+      by = 16 * pn + 4 * j + (v - (j == 0 ? 0 : (j == 1 ? 16 : (j == 2 ? 28 : 36))));
+    }
+    if (by * NP >= p.R) return;                    // (the last panel is enumerated in full)
   }
   const int q0 = bx * PIX, k0 = by * NP;
   // byte offset of the patch origin of a query / key row inside THIS image, or an out-of-range offset: both
@@ -1477,8 +1492,8 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       if (e != hipSuccess) return e;
       dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
       if (p.sym) {
-        const int ny = grid.y, G = ny / 4;
-        p.symT = 2 * G * (G + 1) + (ny - 4 * G) * (G + 1);
+        const int np = ((int)grid.y + 15) / 16;      // panels of 16 key tiles
+        p.symT = 32 * np * np + 8 * np;
         grid = dim3((unsigned)(p.symT * p.B));
       }
       set_launch_grid((long)grid.x * grid.y * grid.z);
@@ -1491,8 +1506,8 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       if (e != hipSuccess) return e;
       dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
       if (p.sym) {
-        const int ny = grid.y, G = ny / 4;
-        p.symT = 2 * G * (G + 1) + (ny - 4 * G) * (G + 1);
+        const int np = ((int)grid.y + 15) / 16;      // panels of 16 key tiles
+        p.symT = 32 * np * np + 8 * np;
         grid = dim3((unsigned)(p.symT * p.B));
       }
       set_launch_grid((long)grid.x * grid.y * grid.z);

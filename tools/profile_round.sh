@@ -3,6 +3,7 @@
 #   <cfg>_bench.json          python bench.py ... (cpu_baseline + parity + live PMC traffic for the headline config)
 #   <cfg>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (per-kernel calls / avg duration)
 #   <cfg>_pmc_summary.txt     three separate --pmc passes (SQ busy counters, FETCH_SIZE, WRITE_SIZE), tools/pmc_summary.py
+#   <cfg>_kernel_seq.txt      per-launch durations of one forward in launch order (tools/kernel_seq.py)
 # Everything lands under gpurun_out/<tag>/; copy into profiles/ afterwards.   usage: tools/profile_round.sh <tag> [cfg ...]
 tag=${1:-r03}; shift
 cfgs=${@:-"c2 c3 c5 b1"}
@@ -15,13 +16,17 @@ profile() {   # name, bench args
   name=$1; shift
   cd /tmp
   B="python $root/bench.py $* --steps 5 --warmup 2 $Q"
-  rocprofv3 --kernel-trace --stats -d $out/${name}_prof -o $name -- $B > $out/${name}_bench_under_rocprof.json 2> $out/${name}_prof.err
+  timeout 300 rocprofv3 --kernel-trace --stats -d $out/${name}_prof -o $name -- $B > $out/${name}_bench_under_rocprof.json 2> $out/${name}_prof.err
   P="python $root/bench.py $* --steps 1 --warmup 1 $Q"
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     -d $out/${name}_pmc1 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc1.err
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${name}_pmc2 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc2.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${name}_pmc3 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc3.err
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${name}_pmc2 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc2.err
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${name}_pmc3 --output-format csv -- $P > /dev/null 2> $out/${name}_pmc3.err
+  # launch sequence of one forward (no in-library events between the launches): tools/kernel_seq.py
+  timeout 300 rocprofv3 --kernel-trace -d $out/${name}_seq --output-format csv -- $P > /dev/null 2> $out/${name}_seq.err
   cd $root
+  python tools/kernel_seq.py $(find $out/${name}_seq -name "*kernel_trace.csv" | head -1) > $out/${name}_kernel_seq.txt 2>> $out/${name}_seq.err
+  rm -rf $out/${name}_seq
   python tools/rocprof_summary.py $(find $out/${name}_prof -name "*.db" | head -1) $out/${name}_kernel_stats.csv
   flat=""
   for d in pmc1 pmc2 pmc3; do
