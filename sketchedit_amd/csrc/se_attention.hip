@@ -1490,7 +1490,10 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
       hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
       if (e != hipSuccess) return e;
-      dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+      // key tiles up to Rp, not R: the fused passes read the pad columns R .. Rp - 1 of every row (times kmul = 0) and need them
+      // FINITE; in bf16 mode Rp is a multiple of 64 and a 32-key tile grid over R left columns unwritten (NaN patterns of stale
+      // memory: tools/fuzz_attention.py, round 4).  Keys >= R are zero-filled by the buffer range check: E = 0 there.
+      dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.Rp + NT * 16 - 1) / (NT * 16), p.B);
       if (p.sym) {
         const int np = ((int)grid.y + 15) / 16;      // panels of 16 key tiles
         p.symT = 32 * np * np + 8 * np;
@@ -1504,7 +1507,10 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
       constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
       hipError_t e = ensure_max_lds((const void*)att2_pair_kernel<NT, PT, BF16>, LDS);
       if (e != hipSuccess) return e;
-      dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.R + NT * 16 - 1) / (NT * 16), p.B);
+      // key tiles up to Rp, not R: the fused passes read the pad columns R .. Rp - 1 of every row (times kmul = 0) and need them
+      // FINITE; in bf16 mode Rp is a multiple of 64 and a 32-key tile grid over R left columns unwritten (NaN patterns of stale
+      // memory: tools/fuzz_attention.py, round 4).  Keys >= R are zero-filled by the buffer range check: E = 0 there.
+      dim3 grid((p.R + PT * 64 - 1) / (PT * 64), (p.Rp + NT * 16 - 1) / (NT * 16), p.B);
       if (p.sym) {
         const int np = ((int)grid.y + 15) / 16;      // panels of 16 key tiles
         p.symT = 32 * np * np + 8 * np;

@@ -33,3 +33,41 @@ def test_random_layer_shapes_vs_oracle():
     bad, worst = mod.run(120, 77, verbose=False)
     assert bad == 0
     assert worst["f32"] < 1e-4
+
+
+@pytest.mark.timeout(600)
+def test_random_attention_shapes_vs_oracle():
+    """tools/fuzz_attention.py: the attention op at random feature-map sizes (LDS-staged fused passes where wc % 4 == 0, the
+    round-3 kernels elsewhere; symmetric E GEMM in fp32, fp16 E in bf16 mode), soft to saturated scores, random key validity."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_fuzz_attention", os.path.join(root, "tools", "fuzz_attention.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(150, 3, verbose=False)
+    assert bad == 0
+    assert worst["f32"] < 1e-4 and worst["bf16"] < 2.0 ** -7
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 8), (1, 42, 8), (1, 10, 80), (2, 6, 40)], ids=lambda s: "%dx%dx%d" % s)
+def test_attention_pad_columns_are_finite_in_bf16_mode(shape):
+    """R % 64 in 1..32 in bf16 mode (Rp is a multiple of 64 there, the small-grid E GEMM tiles are 32 keys wide): every column
+    of E up to Rp has to be written, the fused passes read them.  Best effort at hostile stale memory first: 256 MB of NaNs are
+    written and handed back to the driver, from which the op's workspace is allocated next (tools/fuzz_attention.py found the
+    original defect with whatever the box's memory held)."""
+    import numpy as np
+    import torch
+    from oracle import sketchedit_oracle as O
+    from sketchedit_amd import synth
+    from sketchedit_amd._lib import shared_engine
+    eng = shared_engine()
+    B, h, w = shape
+    junk = torch.full((64 << 20,), float("nan"), device="cuda")      # NaN patterns in freshly freed memory
+    torch.cuda.synchronize()
+    del junk
+    torch.cuda.empty_cache()
+    x = synth.uniform(9, "padc.x%d" % h, (B, 96, h, w), -1, 1)
+    full = (synth.uniform(9, "padc.m%d" % h, (B, 1, 4 * h, 4 * w), 0, 1) < 0.5).astype(np.float32)
+    out = eng.attention(torch.from_numpy(x).cuda(), torch.from_numpy(full).cuda(), bf16=True).cpu()
+    ro, _ = O.contextual_attention(torch.from_numpy(x).to(torch.bfloat16).float(), torch.from_numpy(full), torch.bfloat16)
+    assert torch.isfinite(out).all()
+    assert float((out - ro).abs().max()) < 2.0 ** -7 * float(ro.abs().max())

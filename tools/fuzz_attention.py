@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the attention op alone (run on the GPU box): random batch / feature-map size (most widths with
+wc % 4 == 0, i.e. the LDS-staged fused passes, the symmetric E GEMM and -- in bf16 mode -- fp16 E; ragged patch rows, one-chunk
+and many-chunk rows), soft and saturated scores, both precisions, random key validity, against the oracle
+(oracle/sketchedit_oracle.py: contextual_attention).   usage: python tools/fuzz_attention.py [cases] [seed]
+Round 4: 600 cases, 0 failures (worst 2.8e-5 / 7.8e-3 of the largest output, fp32 / bf16) -- after its first 150 cases had found
+NaNs in bf16 mode at R % 64 in 1..32: pad columns of E that the 32-key tile grid never wrote and the fused passes read."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import sketchedit_oracle as O  # noqa: E402
+from sketchedit_amd import synth  # noqa: E402
+from sketchedit_amd._lib import Engine  # noqa: E402
+
+
+def run(n, seed, verbose=True):
+    rng = np.random.RandomState(seed)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    eng = Engine(0)
+    bad, worst = 0, {"f32": 0.0, "bf16": 0.0}
+    t0 = time.time()
+    for k in range(n):
+        B = int(rng.randint(1, 3))
+        h = 2 * int(rng.randint(2, 36))
+        w = 8 * int(rng.randint(1, 17)) if k % 5 else 2 * int(rng.randint(2, 40))      # 4 of 5: wc % 4 == 0
+        bf16 = k % 3 == 2
+        amp = (0.004, 0.02, 1.0)[int(rng.randint(0, 3))]                                # soft ... saturated softmax
+        x = (amp * synth.uniform(100 + k, "fa.x", (B, 96, h, w), -1, 1)).astype(np.float32)
+        full = (synth.uniform(100 + k, "fa.m", (B, 1, 4 * h, 4 * w), 0, 1) < rng.uniform(0.2, 0.9)).astype(np.float32)
+        if k % 4 == 0:
+            full[0, :, :, 2 * w:] = 1.0                                                 # a block of invalid keys
+        out = eng.attention(torch.from_numpy(x).cuda(), torch.from_numpy(full).cuda(), bf16=bf16).cpu()
+        if bf16:
+            ro, _ = O.contextual_attention(torch.from_numpy(x).to(torch.bfloat16).float(), torch.from_numpy(full), torch.bfloat16)
+            tol = 2.0 ** -7 * float(ro.abs().max())
+        else:
+            ro, _ = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
+            tol = 1e-4 * float(ro.abs().max())
+        d = float((out - ro).abs().max())
+        rel = d / max(float(ro.abs().max()), 1e-30)
+        ok = d < tol and np.isfinite(d)
+        worst["bf16" if bf16 else "f32"] = max(worst["bf16" if bf16 else "f32"], rel)
+        bad += 0 if ok else 1
+        if verbose or not ok:
+            print("%3d %-4s B=%d %3dx%-3d amp %.3f  rel %.2e %s" % (k, "bf16" if bf16 else "f32", B, h, w, amp, rel, "ok" if ok else "FAIL"), flush=True)
+    eng.close()
+    print("cases %d  failures %d  worst rel f32 %.2e  bf16 %.2e  (%.0f s)" % (n, bad, worst["f32"], worst["bf16"], time.time() - t0))
+    return bad, worst
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 3)[0] else 0)
