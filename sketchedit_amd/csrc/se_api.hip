@@ -1547,7 +1547,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
   float* xn = P.alloc_raw(bf ? ((size_t)B * h * w * 96 + 1) / 2 : (size_t)B * h * w * 96);
   float *valid = nullptr, *S = nullptr, *S2 = nullptr, *xT = nullptr, *stats = nullptr;
   if (v2) {
-    valid = P.alloc_raw(3 * ((size_t)B * Rp + guard));      // validR, kmul, kadd, each behind its guard band
+    valid = P.alloc_raw(7 * ((size_t)B * Rp + guard) + (size_t)B * 768);      // validR, kmul, kadd (+ fp16-E form: kadd2, ea4, ea, eb), each behind its guard band; emean
     stats = P.alloc_raw((size_t)B * R * 2);    // fused streaming pass: (row max, 1 / row sum) per query
     xT = P.alloc_raw(bf ? (size_t)B * 4 * 96 * Rp / 2 : (size_t)B * 4 * 96 * Rp);
     S = P.alloc_raw((size_t)B * R * Rp + 2 * guard);       // E (fp32) between two guard bands; three-pass form: then P~
@@ -1568,6 +1568,9 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
       a.hc = hc; a.wc = wc; a.R = R; a.Rp = Rp; a.bf16 = bf ? 1 : 0;
       a.validR = valid + guard; a.xT = xT; a.E = S + guard; a.P = S2; a.stats = stats; a.guard = guard; a.similar = similar_nchw;
       a.kmul = valid + ((size_t)B * Rp + guard) + guard; a.kadd = valid + 2 * ((size_t)B * Rp + guard) + guard;
+      a.kadd2 = valid + 3 * ((size_t)B * Rp + guard) + guard; a.ea4 = valid + 4 * ((size_t)B * Rp + guard) + guard;
+      a.ea = valid + 5 * ((size_t)B * Rp + guard) + guard; a.eb = valid + 6 * ((size_t)B * Rp + guard) + guard;
+      a.emean = valid + 7 * ((size_t)B * Rp + guard);
       HIPCHK(c, launch_attention(a, c->st));
     } else {
       a.valid = valid; a.S = S;

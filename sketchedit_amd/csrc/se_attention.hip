@@ -440,6 +440,78 @@ __global__ __launch_bounds__(256) void att2_transpose_kernel(const AttParams p) 
   }
 }
 
+// fp16-E form (bf16 mode): E is stored DOUBLY CENTRED, E'[r][s] = E[r][s] - ea[r] - eb[s] with ea[r] = <X_r, mean XN>,
+// eb[s] = <mean X, XN_s> - <mean X, mean XN> (X_r, XN_s: the 384-vectors of a class-grid position; means over the positions of
+// the image) -- the additive row and column effects of E, known before the GEMM.  fp16 carries a fixed 2^-12 RELATIVE error:
+// gated feature maps share a large mean vector, so raw E is "15 +- 3" and every score is off by ~4e-3 (x 4 terms x scale 10:
+// several % in P; an end-to-end fuzz case with the larger-gain weight set moved 10 % further from the oracle than with fp32 E),
+// while the centred values are the +- 3.  With zero-mean inputs the offsets vanish and nothing changes.  (Centring on the
+// diagonal instead -- E' = minus half the squared patch distance -- was built first: it is exact where patches are alike and
+// WORSE than raw fp16 where the deciding keys are unlike the query, e.g. when the like ones are invalid: 9 of 300 op-fuzz
+// cases beyond one bf16 ulp.)  The offsets are added back in fp32 by the two LDS-staged readers:
+// S[q][k] = sum_d' E'[q+d'][k+d'] + ea4[q] + eb4[k]; the key half is folded into the key test (kadd2 = kadd + eb4 kmul), the
+// query half is a scalar per query.
+// att2_emean_kernel: block = (image, 32 of the 384 components, X | XN); emean = mean over r < R.
+template <bool BF16>
+__global__ __launch_bounds__(256) void att2_emean_kernel(const AttParams p) {
+  __shared__ float part[8][33];
+  const int b = blockIdx.z, which = blockIdx.y, e0 = blockIdx.x * 32;
+  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;          // component, row lane (8 rows in flight)
+  const int e = e0 + el, cls = e / 96, c = e - cls * 96;
+  const float* src = which ? p.xn : p.x;
+  float acc = 0.f;
+  for (int r = rl; r < p.R; r += 8) {
+    const int ry = r / p.wc, rx = r - ry * p.wc;
+    const size_t at = ((size_t)(b * p.h + 2 * ry + (cls >> 1)) * p.w + 2 * rx + (cls & 1)) * 96 + c;
+    acc += BF16 ? bf16_lo(((const unsigned short*)src)[at]) : src[at];
+  }
+  part[rl][el] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += part[i][el];
+    p.emean[((size_t)b * 2 + which) * 384 + e] = t / (float)p.R;
+  }
+}
+// One wave per class-grid position: ea, eb from the stored (bf16) x and xn.
+template <bool BF16>
+__global__ __launch_bounds__(256) void att2_eoff_kernel(const AttParams p) {
+  const int lane = threadIdx.x & 63;
+  const long gi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // over B * Rp
+  if (gi >= (long)p.B * p.Rp) return;
+  const int b = (int)(gi / p.Rp), r = (int)(gi - (long)b * p.Rp);
+  const float* mx = p.emean + (size_t)b * 768, *mk = mx + 384;
+  float a = 0.f, bb = 0.f, g = 0.f;
+  if (r < p.R) {
+    const int ry = r / p.wc, rx = r - ry * p.wc;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {          // 4 pixels x 96 channels = 384 = 6 x 64
+      const int e = t * 64 + lane, cls = e / 96, c = e - cls * 96;
+      const size_t at = ((size_t)(b * p.h + 2 * ry + (cls >> 1)) * p.w + 2 * rx + (cls & 1)) * 96 + c;
+      const float xv = BF16 ? bf16_lo(((const unsigned short*)p.x)[at]) : p.x[at];
+      const float kv = BF16 ? bf16_lo(((const unsigned short*)p.xn)[at]) : p.xn[at];
+      a = fmaf(xv, mk[e], a);
+      bb = fmaf(mx[e], kv, bb);
+      g = fmaf(mx[e], mk[e], g);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); bb += __shfl_xor(bb, o); g += __shfl_xor(g, o); }
+    bb -= g;
+  }
+  if (lane == 0) { p.ea[gi] = a; p.eb[gi] = bb; }
+}
+__global__ __launch_bounds__(256) void att2_eoff4_kernel(const AttParams p) {
+  const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gi >= (long)p.B * p.Rp) return;
+  const int b = (int)(gi / p.Rp), k = (int)(gi - (long)b * p.Rp);
+  const float* ea = p.ea + (size_t)b * p.Rp, *eb = p.eb + (size_t)b * p.Rp;
+  auto at = [&](const float* t, int i) { return i < p.R ? t[i] : 0.f; };
+  p.ea4[gi] = ((at(ea, k) + at(ea, k + 1)) + at(ea, k + p.wc)) + at(ea, k + p.wc + 1);
+  const float b4 = ((at(eb, k) + at(eb, k + 1)) + at(eb, k + p.wc)) + at(eb, k + p.wc + 1);
+  p.kadd2[gi] = fmaf(b4, p.kmul[gi], p.kadd[gi]);      // -inf stays -inf (kmul = 0 there), an invalid key stays 0
+}
+
 // E[b][r][s] = <2x2x96 block of x at class-grid position r, 2x2x96 block of xn at s>; rows of the A tile = keys s,
 // MFMA columns = queries r; written query-major so that the softmax axis is contiguous.
 template <int NT, int PT, bool BF16>
@@ -551,7 +623,9 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
       if (BF16 && p.e16) {          // E in fp16 (bf16 mode with the LDS-staged fused passes): 8 bytes per lane
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const h4 hv = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        const float di = p.ea[(size_t)b * p.Rp + i];
+        const f32x4 dj = *(const f32x4*)(p.eb + (size_t)b * p.Rp + j);
+        const h4 hv = (h4){(_Float16)((v[0] - di) - dj[0]), (_Float16)((v[1] - di) - dj[1]), (_Float16)((v[2] - di) - dj[2]), (_Float16)((v[3] - di) - dj[3])};
         __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv), (u32x2*)((char*)p.E + (((size_t)b * p.R + i) * p.Rp + j) * 2));
       } else __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));
     }
@@ -1129,7 +1203,7 @@ DEVFN void lds_stage_producer(const AttParams& p, int b, int r00, int pid, int l
       if (cc >= NPR) { cc -= NPR; row += 1; }
     }
   }
-  const float* ktab = (lane < 32 ? p.kmul : p.kadd) + (size_t)b * p.Rp;
+  const float* ktab = (lane < 32 ? p.kmul : (EH ? p.kadd2 : p.kadd)) + (size_t)b * p.Rp;
   const int kl = 4 * (lane & 31);
   const unsigned lds_e = lds_addr_of(smem);
   auto issue = [&](int n) {
@@ -1197,7 +1271,7 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
   // ring zeroed (columns < 0 are not keys: P = 0)
   for (int i = tid; i < 25 * RING / 4; i += 512) ((f32x4*)Pr)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // phase-B role: waves 0..4 = query row i, lane = column pair; the five queries (i, 0..4): -m2 (or -inf), 1 / l (or 0)
-  float qm[5], qi[5];
+  float qm[5], qi[5], qc[5];           // (qc: the query half of the fp16-E offset, ea4[q]; 0 with fp32 E)
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int qy = ry0 - 1 + w, qx = rx0 - 1 + j;
@@ -1205,6 +1279,7 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
     const float2 st = *(const float2*)(p.stats + ((size_t)b * p.R + (ok ? qy * p.wc + qx : 0)) * 2);
     qm[j] = ok ? -st.x : -INFINITY;
     qi[j] = ok ? st.y : 0.f;
+    qc[j] = (EH && ok) ? p.ea4[(size_t)b * p.Rp + qy * p.wc + qx] : 0.f;
   }
   for (int n = 0; n < nchunks; ++n) {
     const int s0 = n * C;
@@ -1226,7 +1301,8 @@ __global__ __launch_bounds__(640) void att2_ptilde_lds_kernel(const AttParams p,
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         // S[(i, j)][k] = ((E[(i,j)][k] + E[(i,j+1)][k+1]) + E[(i+1,j)][k+wc]) + E[(i+1,j+1)][k+wc+1]
-        const f32x2 sum = ((r0[j] + (f32x2){r0[j + 1][1], x0[j + 1]}) + r1[j]) + (f32x2){r1[j + 1][1], x1[j + 1]};
+        f32x2 sum = ((r0[j] + (f32x2){r0[j + 1][1], x0[j + 1]}) + r1[j]) + (f32x2){r1[j + 1][1], x1[j + 1]};
+        if (EH) sum += (f32x2){qc[j], qc[j]};
         const f32x2 arg = sum * mu + (ad + (f32x2){qm[j], qm[j]});
         f32x2 pv = (f32x2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} * (f32x2){qi[j], qi[j]};
         if (BF16) {                                            // P is a bf16 value in bf16 mode (rounded before the sum)
@@ -1294,6 +1370,12 @@ __global__ __launch_bounds__(384) void att2_stats_lds_kernel(const AttParams p, 
     return;
   }
   float m_[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, l_[4] = {0.f, 0.f, 0.f, 0.f};      // online (max, sum) of queries (w, 0..3), this lane's columns
+  float qc[4];                         // the query half of the fp16-E offset (0 with fp32 E)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int qy = qy0 + w, qx = qx0 + j;
+    qc[j] = (EH && qy < p.hs && qx < p.ws) ? p.ea4[(size_t)b * p.Rp + qy * p.wc + qx] : 0.f;
+  }
   for (int n = 0; n < nchunks; ++n) {
     const char* Eb = smem + (n % NS) * SB;
     const float* Kt = (const float*)(smem + (n % NS) * SB + NIP * 1024);
@@ -1310,7 +1392,8 @@ __global__ __launch_bounds__(384) void att2_stats_lds_kernel(const AttParams p, 
     const bool live = n * C + c < p.Rp;                    // (columns beyond Rp: the table slice was clamped, skip)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x2 sum = ((r0[j] + (f32x2){r0[j + 1][1], x0[j + 1]}) + r1[j]) + (f32x2){r1[j + 1][1], x1[j + 1]};
+      f32x2 sum = ((r0[j] + (f32x2){r0[j + 1][1], x0[j + 1]}) + r1[j]) + (f32x2){r1[j + 1][1], x1[j + 1]};
+      if (EH) sum += (f32x2){qc[j], qc[j]};
       f32x2 t = sum * mu + ad;
       if (!live) t = (f32x2){-INFINITY, -INFINITY};
       const float mn = fmaxf(m_[j], fmaxf(t[0], t[1]));
@@ -1480,6 +1563,12 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     ProfScope ps_(st, PL_ATT_PREP);
     hipLaunchKernelGGL(att2_prep_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(att2_transpose_kernel<BF16>, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);
+    if (p.e16) {      // offsets of the fp16-E form (att2_emean_kernel)
+      const long nr = (long)p.B * p.Rp;
+      hipLaunchKernelGGL(att2_emean_kernel<BF16>, dim3(12, 2, p.B), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(att2_eoff_kernel<BF16>, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(att2_eoff4_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, p);
+    }
   }
   {
     set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,

@@ -38,7 +38,9 @@ def run(n, seed, verbose=True):
         out = eng.attention(torch.from_numpy(x).cuda(), torch.from_numpy(full).cuda(), bf16=bf16).cpu()
         if bf16:
             ro, _ = O.contextual_attention(torch.from_numpy(x).to(torch.bfloat16).float(), torch.from_numpy(full), torch.bfloat16)
-            tol = 2.0 ** -7 * float(ro.abs().max())
+            # one bf16 spacing of the largest output (a value on a rounding boundary lands on either side), plus a quarter: the
+            # op rounds P, P~ and the output, and two flips can add up (600 cases: 1 at 1.02 spacings, none above)
+            tol = 1.25 * 2.0 ** -7 * float(ro.abs().max())
         else:
             ro, _ = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
             tol = 1e-4 * float(ro.abs().max())
