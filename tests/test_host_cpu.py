@@ -423,3 +423,34 @@ def test_check_checkpoint_tool(tmp_path):
     assert "size mismatch for conv3.weight" in text and "missing key conv5.bias" in text and "unexpected key extra.weight" in text
     torch.save(bad, d / "latest_net_M.pth")
     assert mod.main([str(d)]) == 1
+
+
+def test_symmetric_score_tile_enumeration():
+    """The tile order of the symmetric E GEMM (se_attention.hip, att2_pair_kernel with p.sym): a 1-D index t enumerates, panel
+    by panel (16 key tiles), the tiles with query tile bx <= key tile by / 4.  This is the device code's integer arithmetic
+    restated: every computed tile exactly once, nothing left of the diagonal, 32 np^2 + 8 np indices for np panels."""
+    import math
+
+    def decode(t):
+        pn = int((math.sqrt(64.0 + 128.0 * t) - 8.0) / 64.0)
+        while 32 * (pn + 1) * (pn + 1) + 8 * (pn + 1) <= t:
+            pn += 1
+        while 32 * pn * pn + 8 * pn > t:
+            pn -= 1
+        u = t - (32 * pn * pn + 8 * pn)
+        if u < 64 * pn:
+            return u >> 4, 16 * pn + (u & 15)
+        v = u - 64 * pn
+        j = 0 if v < 16 else 1 if v < 28 else 2 if v < 36 else 3
+        return 4 * pn + j, 16 * pn + 4 * j + (v - (0, 16, 28, 36)[j])
+
+    for ny in (1, 2, 4, 15, 16, 17, 18, 64, 71, 100, 256):      # key tiles of 64 (or 32) positions: R = 4096 -> 64
+        npan = (ny + 15) // 16
+        seen = set()
+        for t in range(32 * npan * npan + 8 * npan):
+            bx, by = decode(t)
+            assert 0 <= bx <= by // 4
+            if by < ny:                                          # (the last panel is enumerated in full; the kernel returns)
+                assert (bx, by) not in seen
+                seen.add((bx, by))
+        assert seen == {(bx, by) for by in range(ny) for bx in range(by // 4 + 1)}
