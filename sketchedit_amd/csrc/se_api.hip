@@ -1547,7 +1547,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
   float* xn = P.alloc_raw(bf ? ((size_t)B * h * w * 96 + 1) / 2 : (size_t)B * h * w * 96);
   float *valid = nullptr, *S = nullptr, *S2 = nullptr, *xT = nullptr, *stats = nullptr;
   if (v2) {
-    valid = P.alloc_raw(7 * ((size_t)B * Rp + guard) + (size_t)B * 768);      // validR, kmul, kadd (+ fp16-E form: kadd2, ea4, ea, eb), each behind its guard band; emean
+    valid = P.alloc_raw(7 * ((size_t)B * Rp + guard) + (size_t)B * 768 + (size_t)B * hc * 384);      // validR, kmul, kadd (+ fp16-E form: kadd2, ea4, ea, eb), each behind its guard band; emean, epart
     stats = P.alloc_raw((size_t)B * R * 2);    // fused streaming pass: (row max, 1 / row sum) per query
     xT = P.alloc_raw(bf ? (size_t)B * 4 * 96 * Rp / 2 : (size_t)B * 4 * 96 * Rp);
     S = P.alloc_raw((size_t)B * R * Rp + 2 * guard);       // E (fp32) between two guard bands; three-pass form: then P~
@@ -1570,7 +1570,7 @@ int run_attention(se_ctx* c, Plan& P, Act& x, const float* mask_full, Act& out, 
       a.kmul = valid + ((size_t)B * Rp + guard) + guard; a.kadd = valid + 2 * ((size_t)B * Rp + guard) + guard;
       a.kadd2 = valid + 3 * ((size_t)B * Rp + guard) + guard; a.ea4 = valid + 4 * ((size_t)B * Rp + guard) + guard;
       a.ea = valid + 5 * ((size_t)B * Rp + guard) + guard; a.eb = valid + 6 * ((size_t)B * Rp + guard) + guard;
-      a.emean = valid + 7 * ((size_t)B * Rp + guard);
+      a.emean = valid + 7 * ((size_t)B * Rp + guard); a.epart = a.emean + (size_t)B * 768;
       HIPCHK(c, launch_attention(a, c->st));
     } else {
       a.valid = valid; a.S = S;
@@ -2119,7 +2119,7 @@ int se_attention_ex(se_ctx* c, void* stream, const float* x, const float* mask_f
   begin_call(c, stream, exec_flags & SE_FLAG_BF16);
   const bool bf = c->bf16;
   const int R = (h / 2) * (w / 2), Rp = att_row_stride(R, true) + 64;
-  const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (3 + 4 * 96) + 64 * 96 * B + 2 * (size_t)B * R + 5 * (size_t)(w / 2 + 72)) * 4 + (1 << 16);
+  const size_t bytes = ((size_t)B * h * w * 96 * 3 + 2 * (size_t)B * R * Rp + (size_t)B * Rp * (7 + 4 * 96) + 64 * 96 * B + 2 * (size_t)B * R + 9 * (size_t)(w / 2 + 72) + (size_t)B * (768 + (h / 2) * 384)) * 4 + (1 << 16);
   char* ws = nullptr;
   HIPCHK(c, hipMalloc(&ws, bytes));
   c->arena.reset(ws, bytes, false);

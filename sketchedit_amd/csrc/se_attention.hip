@@ -58,34 +58,8 @@ __global__ __launch_bounds__(256) void att_score_kernel(const AttParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (p.sym) {
-    // 1-D grid over the computed tiles only (bx <= by / 4), every XCD a contiguous range (xcd_tile).  Order: image, PANEL of 16
-    // key tiles (by = 16 pn .. + 15), query tile bx, key tile -- the 64 workgroups resident on an XCD are 4 query tiles x the 16
-    // key tiles of one panel: 3.1 MB of operands in its 4 MB L2 for 64 tiles (49 KB per tile instead of 491), and the panel's
-    // keys stay there for every bx.  (by-major order without the XCD remap: 967 MB fetched per launch at R = 4096 B=8 for
-    // 100 MB of operands, and the kernel is then partly bound by that.)  Panel pn holds 64 pn full tiles + the 16 + 12 + 8 + 4
-    // of its diagonal blocks; 32 pn^2 + 8 pn tiles before it.
-    static_assert(PIX == 4 * NP, "tile enumeration");
-    const int lb = xcd_tile(blockIdx.x, gridDim.x);
-    b = lb / p.symT;
-    const int t = lb - b * p.symT;
-    int pn = (int)((sqrtf(64.f + 128.f * (float)t) - 8.f) * (1.f / 64.f));
-    while (32 * (pn + 1) * (pn + 1) + 8 * (pn + 1) <= t) ++pn;
-    while (32 * pn * pn + 8 * pn > t) --pn;
-    const int u = t - (32 * pn * pn + 8 * pn);
-    if (u < 64 * pn) {
-      bx = u >> 4;
-      by = 16 * pn + (u & 15);
-    } else {
-      const int v = u - 64 * pn;
-      const int j = v < 16 ? 0 : (v < 28 ? 1 : (v < 36 ? 2 : 3));
-      bx = 4 * pn + j;
-      by = 16 * pn + 4 * j + (v - (j == 0 ? 0 : (j == 1 ? 16 : (j == 2 ? 28 : 36))));
-    }
-    if (by * NP >= p.R) return;                    // (the last panel is enumerated in full)
-  }
-  const int q0 = bx * PIX, k0 = by * NP;
+  const int b = blockIdx.z;
+  const int q0 = blockIdx.x * PIX, k0 = blockIdx.y * NP;
   // byte offset of the patch origin of a query / key row inside THIS image, or an out-of-range offset: both
   // operands are staged through buffer resources (hardware zero fill, one VALU add per granule; se_gconv.hip)
   auto origin = [&](int i) -> unsigned {
@@ -384,7 +358,8 @@ __global__ void att2_prep_kernel(const AttParams p) {
       const long pix = idx / 24;
       const int b = pix / (p.h * p.w);
       const f32x4 v = *(const f32x4*)(p.x + idx * 4);
-      const f32x4 r = *(const f32x4*)(p.rn + b * 96 + cg * 4);
+      f32x4 r = *(const f32x4*)(p.rn + b * 96 + cg * 4);
+      if (p.sym) r = (f32x4){sqrtf(r[0]), sqrtf(r[1]), sqrtf(r[2]), sqrtf(r[3])};      // symmetric operands (att2_pair_kernel)
       *(f32x4*)(p.xn + idx * 4) = v * r;                        // splitcam.py:40
     }
   }
@@ -451,28 +426,28 @@ __global__ __launch_bounds__(256) void att2_transpose_kernel(const AttParams p) 
 // cases beyond one bf16 ulp.)  The offsets are added back in fp32 by the two LDS-staged readers:
 // S[q][k] = sum_d' E'[q+d'][k+d'] + ea4[q] + eb4[k]; the key half is folded into the key test (kadd2 = kadd + eb4 kmul), the
 // query half is a scalar per query.
-// att2_emean_kernel: block = (image, 32 of the 384 components, X | XN); emean = mean over r < R.
+// att2_emean1/2_kernel: the mean query block, deterministic two-stage sum (class-grid row partials, then rows in order); the
+// mean KEY block is taken as rn * mean X (xn = x rn up to its bf16 rounding: the offsets need not be the exact means, only
+// the same numbers in E' and in the add-back).  (A first one-stage kernel -- 24 blocks per image looping over all rows -- took
+// 192 us at 512x512 B=16, more than fp16 E saves.)
 template <bool BF16>
-__global__ __launch_bounds__(256) void att2_emean_kernel(const AttParams p) {
-  __shared__ float part[8][33];
-  const int b = blockIdx.z, which = blockIdx.y, e0 = blockIdx.x * 32;
-  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;          // component, row lane (8 rows in flight)
-  const int e = e0 + el, cls = e / 96, c = e - cls * 96;
-  const float* src = which ? p.xn : p.x;
+__global__ __launch_bounds__(384) void att2_emean1_kernel(const AttParams p) {
+  const int ry = blockIdx.x, b = blockIdx.y, e = threadIdx.x, cls = e / 96, c = e - cls * 96;
+  const size_t row0 = ((size_t)(b * p.h + 2 * ry + (cls >> 1)) * p.w + (cls & 1)) * 96 + c;
   float acc = 0.f;
-  for (int r = rl; r < p.R; r += 8) {
-    const int ry = r / p.wc, rx = r - ry * p.wc;
-    const size_t at = ((size_t)(b * p.h + 2 * ry + (cls >> 1)) * p.w + 2 * rx + (cls & 1)) * 96 + c;
-    acc += BF16 ? bf16_lo(((const unsigned short*)src)[at]) : src[at];
+  for (int rx = 0; rx < p.wc; ++rx) {
+    const size_t at = row0 + (size_t)rx * 192;
+    acc += BF16 ? bf16_lo(((const unsigned short*)p.x)[at]) : p.x[at];
   }
-  part[rl][el] = acc;
-  __syncthreads();
-  if (rl == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += part[i][el];
-    p.emean[((size_t)b * 2 + which) * 384 + e] = t / (float)p.R;
-  }
+  p.epart[((size_t)b * p.hc + ry) * 384 + e] = acc;
+}
+__global__ __launch_bounds__(384) void att2_emean2_kernel(const AttParams p) {
+  const int b = blockIdx.x, e = threadIdx.x, c = e % 96;
+  float acc = 0.f;
+  for (int ry = 0; ry < p.hc; ++ry) acc += p.epart[((size_t)b * p.hc + ry) * 384 + e];
+  const float m = acc / (float)p.R;
+  p.emean[(size_t)b * 768 + e] = m;
+  p.emean[(size_t)b * 768 + 384 + e] = m * p.rn[b * 96 + c];
 }
 // One wave per class-grid position: ea, eb from the stored (bf16) x and xn.
 template <bool BF16>
@@ -529,30 +504,48 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   // (an image-major 1-D grid with one contiguous range per XCD was measured: no gain in fp32, 0.47 -> 0.67 ms in bf16
   // where the kernel is bound by the 1 GB of E it writes -- the plain 3-D grid spreads those writes over all XCDs)
   int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (p.sym) {      // 1-D grid over the computed tiles only: (image, t), t enumerates (key tile by, query tile bx <= by / 4), bx fastest
+  if (p.sym) {
+    // 1-D grid over the computed tiles only (bx <= by / 4), every XCD a contiguous range (xcd_tile).  Order: image, PANEL of 16
+    // key tiles (by = 16 pn .. + 15), query tile bx, key tile -- the 64 workgroups resident on an XCD are 4 query tiles x the 16
+    // key tiles of one panel: 3.1 MB of operands in its 4 MB L2 for 64 tiles (49 KB per tile instead of 491), and the panel's
+    // keys stay there for every bx.  (by-major order without the XCD remap: 967 MB fetched per launch at R = 4096 B=8 for
+    // 100 MB of operands, and the kernel is then partly bound by that.)  Panel pn holds 64 pn full tiles + the 16 + 12 + 8 + 4
+    // of its diagonal blocks; 32 pn^2 + 8 pn tiles before it.
     static_assert(PIX == 4 * NP, "tile enumeration");
-    b = blockIdx.x / p.symT;
-    const int t = blockIdx.x - b * p.symT;
-    int g = (int)((sqrtf(1.f + 2.f * (float)t) - 1.f) * 0.5f);      // group g = by / 4 holds 4 (g + 1) tiles, 2 g (g + 1) before it
-    while (2 * (g + 1) * (g + 2) <= t) ++g;
-    while (2 * g * (g + 1) > t) --g;
-    const int rem = t - 2 * g * (g + 1), yy = rem / (g + 1);
-    by = 4 * g + yy;
-    bx = rem - yy * (g + 1);
+    const int lb = xcd_tile(blockIdx.x, gridDim.x);
+    b = lb / p.symT;
+    const int t = lb - b * p.symT;
+    int pn = (int)((sqrtf(64.f + 128.f * (float)t) - 8.f) * (1.f / 64.f));
+    while (32 * (pn + 1) * (pn + 1) + 8 * (pn + 1) <= t) ++pn;
+    while (32 * pn * pn + 8 * pn > t) --pn;
+    const int u = t - (32 * pn * pn + 8 * pn);
+    if (u < 64 * pn) {
+      bx = u >> 4;
+      by = 16 * pn + (u & 15);
+    } else {
+      const int v = u - 64 * pn;
+      const int j = v < 16 ? 0 : (v < 28 ? 1 : (v < 36 ? 2 : 3));
+      bx = 4 * pn + j;
+      by = 16 * pn + 4 * j + (v - (j == 0 ? 0 : (j == 1 ? 16 : (j == 2 ? 28 : 36))));
+    }
+    if (by * NP >= p.R) return;                    // (the last panel is enumerated in full)
   }
   const int q0 = bx * PIX, k0 = by * NP;
-  // E is symmetric: E[r][s] = sum_c x[r][c] x[s][c] rn[c] (the key normalisation is per CHANNEL, splitcam.py:40), so with
-  // p.sym (fp32 mode) only the tiles with k0 >= q0 are computed: a tile right of its diagonal block (k0 >= q0 + PIX) also
-  // stores its transpose, which is exactly the set of tiles skipped here (the mirrored value is sum x[s] fl(x[r] rn) instead of
-  // sum x[r] fl(x[s] rn): two roundings per term either way).  53 % of the tiles at R = 4096; the grid holds only those (a 3-D
-  // grid whose left-of-diagonal workgroups returned at once measured NO gain: 0.786 -> 0.805 ms).
+  // E is symmetric: E[r][s] = sum_c x[r][c] x[s][c] rn[c] (the key normalisation is per CHANNEL, splitcam.py:40).  With p.sym
+  // (fp32 mode) BOTH operands are y = x sqrt(rn) (att2_prep_kernel writes that instead of xn = x rn): the products of (r, s)
+  // and (s, r) are then the same numbers in the same k order, E[r][s] == E[s][r] BITWISE, and only the tiles with k0 >= q0 are
+  // computed: a tile right of its diagonal block (k0 >= q0 + PIX) also stores its transpose, which is exactly the set of tiles
+  // left out.  (Mirroring sum x[r] fl(x[s] rn) was built first: equal to rounding only, and WHICH entries are mirrored depends
+  // on the tile shape -- the 128 x 32 tiles of a small call against the 256 x 64 of a large one -- so an image's result depended
+  // on the batch it came in: test_full_size_properties.)  53 % of the tiles at R = 4096; the grid holds only those (a 3-D grid
+  // whose left-of-diagonal workgroups returned at once measured NO gain: 0.786 -> 0.805 ms).
   // byte offset of the 2x2 block origin of a row inside THIS image, or an out-of-range offset (hardware zero fill)
   auto origin = [&](int i) -> unsigned {
     if (i >= p.R) return 0x80000000u;
     const int ry = i / p.wc, rx = i - ry * p.wc;
     return (unsigned)(((2 * ry) * p.w + 2 * rx) * PXB);
   };
-  const se_i32x4 rs_q = make_rsrc((const char*)p.x + (size_t)b * p.h * p.w * PXB, (unsigned)p.h * p.w * (unsigned)PXB);
+  const se_i32x4 rs_q = make_rsrc((const char*)(p.sym ? p.xn : p.x) + (size_t)b * p.h * p.w * PXB, (unsigned)p.h * p.w * (unsigned)PXB);
   const se_i32x4 rs_k = make_rsrc((const char*)p.xn + (size_t)b * p.h * p.w * PXB, (unsigned)p.h * p.w * (unsigned)PXB);
   unsigned qo[NX], ko[NW];
 #pragma unroll
@@ -585,6 +578,20 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (BF16 && p.e16) {
+    // fp16-E form: the accumulators start at -(ea[query] + eb[key]), so the doubly centred E' comes out of the GEMM itself
+    // (20 loads per lane under the first stage; an epilogue that subtracted the offsets row by row cost 90 us at 512x512 B=16)
+    const float* ea = p.ea + (size_t)b * p.Rp, *eb = p.eb + (size_t)b * p.Rp;
+    float eq[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) eq[pt] = ea[min(q0 + w * PT * 16 + pt * 16 + (lane & 15), p.Rp - 1)];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 ek = *(const f32x4*)(eb + min(k0 + nt * 16 + (lane >> 4) * 4, p.Rp - 4));
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = (f32x4){-(eq[pt] + ek[0]), -(eq[pt] + ek[1]), -(eq[pt] + ek[2]), -(eq[pt] + ek[3])};
+    }
+  }
   constexpr int NCH = BF16 ? 6 : 12;   // 4 pixels * 96 ch / (64 | 32)
   stage(0, 0);
   dma_wait_all();
@@ -623,14 +630,12 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
       if (BF16 && p.e16) {          // E in fp16 (bf16 mode with the LDS-staged fused passes): 8 bytes per lane
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const float di = p.ea[(size_t)b * p.Rp + i];
-        const f32x4 dj = *(const f32x4*)(p.eb + (size_t)b * p.Rp + j);
-        const h4 hv = (h4){(_Float16)((v[0] - di) - dj[0]), (_Float16)((v[1] - di) - dj[1]), (_Float16)((v[2] - di) - dj[2]), (_Float16)((v[3] - di) - dj[3])};
+        const h4 hv = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};      // (already centred: accumulator start)
         __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv), (u32x2*)((char*)p.E + (((size_t)b * p.R + i) * p.Rp + j) * 2));
       } else __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));
     }
   }
-  if (!BF16 && p.sym == 1 && k0 >= q0 + PIX) {
+  if (!BF16 && p.sym && k0 >= q0 + PIX) {
     // the transposed tile: row = key k0 + kk, 16 lanes write its PT*16 queries (of this wave) as 16-byte pieces
     constexpr int PPM = PT * 4;                      // pieces per mirrored row
     constexpr int RPM = 64 / PPM;                    // mirrored rows per store instruction
@@ -1550,7 +1555,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
   p.Pt = fused ? p.P : p.E;
   // SE_ATT_STATS_LDS=0: att2_stats_kernel instead of the LDS-staged statistics pass.  SE_ATT_E16=0: E stays fp32 in bf16 mode
   // (fp16 E needs both LDS-staged kernels: they are the only readers that convert).
-  p.sym = BF16 ? 0 : (getenv("SE_ATT_SYM") ? atoi(getenv("SE_ATT_SYM")) : 1);      // SE_ATT_SYM=0: every tile of E computed (2: debug, no mirror store)
+  p.sym = (!BF16 && !(getenv("SE_ATT_SYM") && atoi(getenv("SE_ATT_SYM")) == 0)) ? 1 : 0;      // SE_ATT_SYM=0: every tile of E computed, from x and xn = x rn
   const bool stats_lds = !(getenv("SE_ATT_STATS_LDS") && atoi(getenv("SE_ATT_STATS_LDS")) == 0);
   p.e16 = (BF16 && fused && att_lds_form(p.wc) && stats_lds && !(getenv("SE_ATT_E16") && atoi(getenv("SE_ATT_E16")) == 0)) ? 1 : 0;
   {
@@ -1563,9 +1568,10 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     ProfScope ps_(st, PL_ATT_PREP);
     hipLaunchKernelGGL(att2_prep_kernel<BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(att2_transpose_kernel<BF16>, dim3(p.Rp / 32, 4, p.B), dim3(256), 0, st, p);
-    if (p.e16) {      // offsets of the fp16-E form (att2_emean_kernel)
+    if (p.e16) {      // offsets of the fp16-E form (att2_emean1_kernel)
       const long nr = (long)p.B * p.Rp;
-      hipLaunchKernelGGL(att2_emean_kernel<BF16>, dim3(12, 2, p.B), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(att2_emean1_kernel<BF16>, dim3(p.hc, p.B), dim3(384), 0, st, p);
+      hipLaunchKernelGGL(att2_emean2_kernel, dim3(p.B), dim3(384), 0, st, p);
       hipLaunchKernelGGL(att2_eoff_kernel<BF16>, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, st, p);
       hipLaunchKernelGGL(att2_eoff4_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, p);
     }

@@ -286,7 +286,8 @@ struct AttParams {
   float* similar;      // optional (B, L, hs, ws) NCHW copy of P for the unit-test entry point
   int bf16;            // x, xn, xT, P~ (in the E buffer) and out hold bf16; Rp is then a multiple of 64
   int e16;             // set by the launcher: E holds fp16 (bf16 mode, LDS-staged fused passes), as E[r][s] - ea[r] - eb[s]
-  float* emean;        // [B][2][384] fp16-E form: mean over the class-grid positions of the query blocks X_r and of the key blocks XN_s
+  float* emean;        // [B][2][384] fp16-E form: mean over the class-grid positions of the query blocks X_r; rn times that (the key blocks' mean)
+  float* epart;        // [B][hc][384] scratch of that mean's two-stage sum
   float* ea;           // [B][Rp] fp16-E form: row offset <X_r, mean XN>            (0 in the pad)
   float* eb;           // [B][Rp] fp16-E form: column offset <mean X, XN_s> - <mean X, mean XN>
   float* ea4;          // [B][Rp] fp16-E form: ea[q] + ea[q+1] + ea[q+wc] + ea[q+wc+1], the offset of S[q][.] owed to the query
