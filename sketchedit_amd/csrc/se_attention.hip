@@ -11,6 +11,16 @@
 // so the softmax axis is contiguous), row softmax, and P.V fused with the fold as a gather: an output
 // pixel of parity class (py,px) sums the <=4 patches covering it, i.e. one GEMM with
 // K = 4 (covering patch) x L (keys) -- deterministic, no atomics.
+//
+// That is the round-1 patch form (att_* kernels, SE_ATT_V1=1).  What runs is the space-to-depth form of round 2 (att2_*,
+// DESIGN.md 3.3), in this file in launch order:
+//   att2_prep / att2_transpose          keys (fp32: y = x sqrt(rn) for both operands of a bitwise symmetric E), key tables, V^T
+//   att2_emean1/2, att2_eoff, _eoff4    bf16 mode: row / column offsets of the doubly centred fp16 E
+//   att2_pair                           E GEMM (fp32: tiles on / right of the diagonal only, mirrored; panel order per XCD)
+//   att2_stats_lds + att2_ptilde_lds    round 4: statistics and P~ passes on LDS-staged 4 x 4 patches of rows (producer waves)
+//   att2_stats + att2_ptilde4 / 1       round 3: the same fused form as row-streaming kernels (widths the LDS form does not take)
+//   att2_softmax[_reg] + att2_boxsum[4] three-pass form (P materialised: `similar_out`, SE_ATT_FUSED=0)
+//   att2_pv                             P~ . V GEMM per parity class
 #include "se_device.h"
 
 #include <cstdlib>
