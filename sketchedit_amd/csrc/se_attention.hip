@@ -453,8 +453,12 @@ __global__ __launch_bounds__(384) void att2_emean1_kernel(const AttParams p) {
 }
 __global__ __launch_bounds__(384) void att2_emean2_kernel(const AttParams p) {
   const int b = blockIdx.x, e = threadIdx.x, c = e % 96;
-  float acc = 0.f;
-  for (int ry = 0; ry < p.hc; ++ry) acc += p.epart[((size_t)b * p.hc + ry) * 384 + e];
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains: the loop is bound by load latency (16 blocks of 384 threads)
+  for (int ry = 0; ry < p.hc; ry += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ry + u < p.hc) a4[u] += p.epart[((size_t)b * p.hc + ry + u) * 384 + e];
+  const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   const float m = acc / (float)p.R;
   p.emean[(size_t)b * 768 + e] = m;
   p.emean[(size_t)b * 768 + 384 + e] = m * p.rn[b * 96 + c];
