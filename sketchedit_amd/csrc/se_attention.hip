@@ -1533,7 +1533,7 @@ __global__ void att2_similar_kernel(const AttParams p) {
   p.similar[idx] = BF16 ? bf16_lo(((const unsigned short*)p.P)[at]) : p.P[at];
 }
 
-// Which form runs (measured on MI355X; same-box A/B runs of round 4, tools/_build/att_ab.sh; statistics + P~ pass):
+// Which form runs (measured on MI355X; same-box A/B runs of round 4, tools/att_ab.sh; statistics + P~ pass):
 //   256x256 inputs (R = 1024), 32 images:  three-pass 65 + 71 us | fused, round-3 kernels 44 + 89 us | fused, LDS-staged P~ 44 + 81 us
 //   512x512 inputs (R = 4096),  8 images:  three-pass 272 + 269 us | round-3 fused 183 + 410 us | LDS-staged 135 + 263 us
 //       (the round-3 streaming kernel was bound by the L2 -> L1 traffic of its nine source rows per output row; the LDS-staged
