@@ -45,7 +45,7 @@ def test_random_attention_shapes_vs_oracle():
     spec.loader.exec_module(mod)
     bad, worst = mod.run(150, 3, verbose=False)
     assert bad == 0
-    assert worst["f32"] < 1e-4 and worst["bf16"] < 1.25 * 2.0 ** -7
+    assert worst["f32"] < 1e-4 and worst["bf16"] < 1.5 * 2.0 ** -7
 
 
 @pytest.mark.parametrize("shape", [(1, 12, 8), (1, 42, 8), (1, 10, 80), (2, 6, 40)], ids=lambda s: "%dx%dx%d" % s)

@@ -3,7 +3,7 @@
 wc % 4 == 0, i.e. the LDS-staged fused passes, the symmetric E GEMM and -- in bf16 mode -- fp16 E; ragged patch rows, one-chunk
 and many-chunk rows), soft and saturated scores, both precisions, random key validity, against the oracle
 (oracle/sketchedit_oracle.py: contextual_attention).   usage: python tools/fuzz_attention.py [cases] [seed]
-Round 4: 600 cases, 0 failures (worst 2.8e-5 / 7.8e-3 of the largest output, fp32 / bf16) -- after its first 150 cases had found
+Round 4: 1400 cases, 0 failures (worst 3.9e-5 / 1.05e-2 of the largest output, fp32 / bf16; the bf16 bound is 1.5 spacings) -- after its first 150 cases had found
 NaNs in bf16 mode at R % 64 in 1..32: pad columns of E that the 32-key tile grid never wrote and the fused passes read."""
 import os
 import sys
@@ -31,16 +31,22 @@ def run(n, seed, verbose=True):
         w = 8 * int(rng.randint(1, 17)) if k % 5 else 2 * int(rng.randint(2, 40))      # 4 of 5: wc % 4 == 0
         bf16 = k % 3 == 2
         amp = (0.004, 0.02, 1.0)[int(rng.randint(0, 3))]                                # soft ... saturated softmax
+        frac = rng.uniform(0.2, 0.9)
+        only = os.environ.get("SE_FUZZ_ONLY")                   # "542,17": re-run single cases of a sweep (same random draws)
+        if only and str(k) not in only.split(","):
+            continue
         x = (amp * synth.uniform(100 + k, "fa.x", (B, 96, h, w), -1, 1)).astype(np.float32)
-        full = (synth.uniform(100 + k, "fa.m", (B, 1, 4 * h, 4 * w), 0, 1) < rng.uniform(0.2, 0.9)).astype(np.float32)
+        full = (synth.uniform(100 + k, "fa.m", (B, 1, 4 * h, 4 * w), 0, 1) < frac).astype(np.float32)
         if k % 4 == 0:
             full[0, :, :, 2 * w:] = 1.0                                                 # a block of invalid keys
         out = eng.attention(torch.from_numpy(x).cuda(), torch.from_numpy(full).cuda(), bf16=bf16).cpu()
         if bf16:
             ro, _ = O.contextual_attention(torch.from_numpy(x).to(torch.bfloat16).float(), torch.from_numpy(full), torch.bfloat16)
-            # one bf16 spacing of the largest output (a value on a rounding boundary lands on either side), plus a quarter: the
-            # op rounds P, P~ and the output, and two flips can add up (600 cases: 1 at 1.02 spacings, none above)
-            tol = 1.25 * 2.0 ** -7 * float(ro.abs().max())
+            # one bf16 spacing of the largest output (a value on a rounding boundary lands on either side), plus a half: the op
+            # rounds P, P~ and the output, and flips add up; fp16 E (2^-12 relative on every score: ~0.2 % in P, half of P's own
+            # bf16 rounding) moves which entries flip.  1400 cases: 1 at 1.34 spacings (0.67 with fp32 E, SE_ATT_E16=0), 1 at
+            # 1.02, none above; end to end the error triangle has the same distribution with either (tools/fuzz_sizes.py)
+            tol = 1.5 * 2.0 ** -7 * float(ro.abs().max())
         else:
             ro, _ = O.contextual_attention(torch.from_numpy(x), torch.from_numpy(full))
             tol = 1e-4 * float(ro.abs().max())
