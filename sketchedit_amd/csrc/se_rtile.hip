@@ -344,7 +344,12 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
 // MFMAs per wave and 8 x 16 block: 72 / 90 / 126 for 3 / 4 / 5 channels (dense direct: 114 / 150 / 192).
 // Measured (256x256 B=32, same box): gconv_n48 1.85 -> 1.76 ms per step.  A PERSISTENT form (two workgroups per CU, weights
 // resident once, the raw tile of block i+1 DMA'd under the MFMAs of block i) measured the same 1.754 ms and was dropped:
-// with two non-persistent workgroups per CU the other workgroup's MFMAs already cover this one's prologue.
+// with two non-persistent workgroups per CU the other workgroup's MFMAs already cover this one's prologue.  Nor did a
+// WAVE-SPECIALISED persistent form (four MFMA waves: k loop + epilogue; two producer waves: raw-tile DMA two blocks ahead with
+// counted waits, transform one block ahead into a second T buffer; parity green): 1.752 against 1.755 ms, same box, three
+// alternations.  The kernel is not waiting for anything a second workgroup cannot cover: per block pair and SIMD it issues
+// ~4.6k cycles of MFMAs, ~2.6k of other VALU work (transform, the A^T folds: 120 instructions per block, epilogue) that the
+// MFMAs exclude, and ~3.7k cycles' worth of LDS traffic (fragment reads, 32 % bank conflicts on the dword gathers) in 10.6k.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CD>
 __global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams p) {
