@@ -17,6 +17,10 @@
  *    crosses the boundary.  A context serialises its own forwards with an internal mutex, so one
  *    ctx may be shared by threads (demo.py:120 runs Flask threaded) -- one ctx per stream is faster.
  *  - H and W must be multiples of 8 (demo.py:43-45 enforces the same for the reference).
+ *  - Any batch size: the kernels address one tensor with 32-bit byte offsets, so a forward over more images than fit
+ *    2^31 bytes of its largest activation (96 bytes per pixel in fp32: 341 images at 256x256) runs as several passes of
+ *    the same plan over image ranges; an image's result is bit-identical whatever pass (or batch) it is in.  A single
+ *    image beyond that range, and a per-op call beyond it, is an error -- never a silently wrong result.
  */
 #ifndef SKETCHEDIT_HIP_H
 #define SKETCHEDIT_HIP_H
@@ -116,6 +120,17 @@ int se_quantize_u8(se_ctx* ctx, void* stream, const float* composed, const float
  * aggregated per kernel.  se_profile_enable(ctx, 0) switches it off and drops the records. */
 int se_profile_enable(se_ctx* ctx, int on);
 int se_profile_report(se_ctx* ctx, char* buf, size_t cap);
+
+/* ---- developer switches (no reference counterpart; used by the tests and the A/B tools) -----------
+ * The library's kernel-form switches ("SE_WINOGRAD_F43", "SE_ATT_FUSED", ...) live in ONE process-wide
+ * table that is filled from the environment once, at first use; no forward ever calls getenv.  se_debug_set_option
+ * changes an entry for every later call of the process (name with or without the "SE_" prefix; returns 0, or 1 for an
+ * unknown name), se_debug_get_option reads one, se_debug_reset_options restores the environment / built-in values.
+ * "SE_TEST_OFFSET_LIMIT" (settable only here) lowers the byte range the 32-bit-offset kernels may address, so that a
+ * test reaches the large-batch passes of the forwards with a few small images. */
+int se_debug_set_option(const char* name, int value);
+int se_debug_get_option(const char* name, int* value);
+void se_debug_reset_options(void);
 
 /* ---- per-op entry points (unit tests; same kernels as the forwards) ----------------------------
  * gen_conv / gen_deconv (models/networks/utils.py:9-51): x (B,Cin,H,W) device, w (Cout,Cin,k,k) and

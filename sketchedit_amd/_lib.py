@@ -29,7 +29,7 @@ LOW_LATENCY_MAX_PIXELS = 4 * 256 * 256
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
            "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_inference", "se_inference_u8", "se_gated_conv2d",
            "se_gated_conv2d_ex", "se_attention", "se_attention_ex", "se_quantize_u8", "se_profile_enable",
-           "se_profile_report"]
+           "se_profile_report", "se_debug_set_option", "se_debug_get_option", "se_debug_reset_options"]
 
 
 class SketchEditHipError(RuntimeError):
@@ -135,6 +135,12 @@ def load_library():
         lib.se_profile_enable.restype = ci
         lib.se_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
         lib.se_profile_report.restype = ci
+        lib.se_debug_set_option.argtypes = [ctypes.c_char_p, ci]
+        lib.se_debug_set_option.restype = ci
+        lib.se_debug_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci)]
+        lib.se_debug_get_option.restype = ci
+        lib.se_debug_reset_options.argtypes = []
+        lib.se_debug_reset_options.restype = None
         _lib = lib
         return lib
 
@@ -149,6 +155,24 @@ def shared_engine(device=0):
         if device not in _shared:
             _shared[device] = Engine(device)
         return _shared[device]
+
+
+def set_option(name, value):
+    """Developer switch of the library, process-wide, effective from the next call on.  The library
+    reads its switches from the environment ONCE; tests and A/B tools change them afterwards through this call."""
+    if load_library().se_debug_set_option(name.encode(), int(value)):
+        raise SketchEditHipError("unknown developer switch %r" % name)
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    if load_library().se_debug_get_option(name.encode(), ctypes.byref(v)):
+        raise SketchEditHipError("unknown developer switch %r" % name)
+    return v.value
+
+
+def reset_options():
+    load_library().se_debug_reset_options()
 
 
 def flags_from_opt(opt):

@@ -208,9 +208,16 @@ int pack_winoup(se_ctx* c, Layer& L);
 bool winoup48_eligible_layer(const LayerDef& d);
 int pack_winoup48(se_ctx* c, Layer& L);
 
-int xcd_remap_enabled() {      // SE_XCD_REMAP=0 switches the XCD-aware tile order off (A/B measurements)
-  static const int v = getenv("SE_XCD_REMAP") ? atoi(getenv("SE_XCD_REMAP")) : 1;
-  return v;
+int xcd_remap_enabled() { return opt(OPT_XCD_REMAP); }     // SE_XCD_REMAP=0 switches the XCD-aware tile order off (A/B measurements)
+
+// Every raw-tile / Winograd / gather kernel addresses its source through a buffer resource with 32-bit BYTE offsets and uses
+// byte offset 0x80000000 as the "outside the image -> hardware zero fill" sentinel, so a tensor one launch addresses must stay
+// below 2^31 BYTES (the guards used to count elements).  The forwards never reach the limit: they split
+// the batch into passes (batch_passes).  SE_TEST_OFFSET_LIMIT (se_debug_set_option only) lowers it so that the tests reach the
+// split with a handful of small images.
+long long addr_limit() {
+  const int v = opt(OPT_TEST_OFFSET_LIMIT);
+  return v > 0 ? (long long)v : (1ll << 31);
 }
 
 int choose_cfg(int G) {
@@ -866,14 +873,12 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
               int Ho, int Wo, int pad, bool* done) {
   *done = false;
   const LayerDef& d = L.def;
-  static const bool enabled = !(getenv("SE_RTILE") && atoi(getenv("SE_RTILE")) == 0);
-  if (!enabled || src1 || d.stride != 1 || d.rate != 1 || (L.cfg != GC_N48 && L.cfg != GC_N24)) return 0;
+  if (!opt(OPT_RTILE) || src1 || d.stride != 1 || d.rate != 1 || (L.cfg != GC_N48 && L.cfg != GC_N24)) return 0;
   {
     // low-latency mode: only when the tiles still cover the CUs (the small-grid gather-GEMM splits rows over blockIdx.y)
     const int TR0 = rtile_rows(bf);
     const long tiles = (long)B * ((Hin + TR0 - 1) / TR0) * ((Win + 15) / 16) * (d.up ? 4 : 1);
-    static const int ll_min = getenv("SE_RTILE_LL_MIN") ? atoi(getenv("SE_RTILE_LL_MIN")) : 256;
-    if (c->low_latency && tiles < ll_min) return 0;
+    if (c->low_latency && tiles < opt(OPT_RTILE_LL_MIN)) return 0;
   }
   const int es = bf ? 2 : 4, gran = bf ? 8 : 4;
   const int CG = bf ? L.CGp16 : L.CGp, nch = bf ? L.nch16 : L.nch;
@@ -881,8 +886,8 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
   if (!wimg || C0 != CG * gran) return 0;
   // 24 -> 24 3x3: F(2,3) along x on the raw tile (se_rtilew.hip): 160 instead of 224 MFMAs per wave.  SE_RTILE_WX=0: the direct form
   {
-    const char* wx_env = getenv("SE_RTILE_WX");       // (read per call: the tests compare both forms in one process)
-    if (!(wx_env && atoi(wx_env) == 0) && !bf && L.d_wx && d.k == 3 && !d.up && C0 == 24 && d.cin == 24 && d.cout == 24 && (Win % 2) == 0 &&
+    const int wx_mode = opt(OPT_RTILE_WX);
+    if (wx_mode != 0 && !bf && L.d_wx && d.k == 3 && !d.up && C0 == 24 && d.cin == 24 && d.cout == 24 && (Win % 2) == 0 &&
         (long long)B * Hin * Win * 96 < (1ll << 31)) {
       RTileParams p;
       memset(&p, 0, sizeof p);
@@ -893,7 +898,7 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
       udiv_magic_host((unsigned)(p.ty * p.tx), &p.div_cg_m, &p.div_cg_l);      // (reused fields: blk / (ty * tx), t2 / tx)
       udiv_magic_host((unsigned)p.tx, &p.div_rw_m, &p.div_rw_l);
       const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
-      const bool two_d = !(wx_env && atoi(wx_env) == 1) && L.d_wx2 && (Hin % 2) == 0;       // SE_RTILE_WX=1: the one-dimensional form
+      const bool two_d = wx_mode != 1 && L.d_wx2 && (Hin % 2) == 0;       // SE_RTILE_WX=1: the one-dimensional form
       set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
                       (double)B * p.ty * p.tx * 8.0 * (two_d ? 96.0 : 160.0) * 2048.0);       // MFMAs of 16x16x4 per wave and block
       if (two_d) {
@@ -908,14 +913,12 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
     }
   }
   // dense-K form of the 5x5 first layers (fp32): SE_RTILE_DENSE=0 keeps the channel-padded K
-  static const bool dense_on = !(getenv("SE_RTILE_DENSE") && atoi(getenv("SE_RTILE_DENSE")) == 0);
-  if (dense_on && !bf && L.d_wd && L.dense && d.k == 5 && !d.up && L.cfg == GC_N48 && (long long)Hin * Win * C0 * 4 < (1ll << 31)) {
+  if (opt(OPT_RTILE_DENSE) != 0 && !bf && L.d_wd && L.dense && d.k == 5 && !d.up && L.cfg == GC_N48 && (long long)Hin * Win * C0 * 4 < (1ll << 31)) {
     // The kernel addresses its source with 32-bit byte offsets.  A batch beyond that range is run as sub-launches of the
     // SAME kernel form over image ranges (switching to the channel-padded kernel would change the summation
     // order, i.e. the bit-identity of an image's result across batch compositions within one execution mode).
     const long long per_img = (long long)Hin * Win * C0 * 4;
-    const char* lim_env = getenv("SE_TEST_OFFSET_LIMIT");       // test aid: a smaller byte range forces the sub-launches (read per call)
-    const long long lim = lim_env ? atoll(lim_env) : (1ll << 31);
+    const long long lim = addr_limit();       // (SE_TEST_OFFSET_LIMIT, a test aid: a smaller byte range forces the sub-launches)
     const int bmax = (int)std::max<long long>(1, (lim - 1) / per_img);
     for (int b0 = 0; b0 < B; b0 += bmax) {
       const int nb = std::min(bmax, B - b0);
@@ -927,8 +930,7 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
       p.act = d.act; p.xcd = xcd_remap_enabled(); p.dense = L.dense; p.nch = L.nchd; p.NP = 48;
       const double alg = 2.0 * (double)nb * Ho * Wo * d.cout * d.cin * 25;
       // F(2,5) along x (rtile_dense5w_kernel; even widths): 6 positions x ceil(5 Cd / 4) k-steps per 2 outputs.  SE_RTILE_D5W=0: direct
-      const char* d5w_env = getenv("SE_RTILE_D5W");      // (read per call: the tests compare both forms in one process)
-      if (!(d5w_env && atoi(d5w_env) == 0) && L.d_wdw && (Win % 2) == 0) {
+      if (opt(OPT_RTILE_D5W) != 0 && L.d_wdw && (Win % 2) == 0) {
         p.wpk = L.d_wdw; p.dense = L.dense + 100;
         set_launch_cost(alg, 4.0 * ((double)nb * Hin * Win * d.cin + (double)nb * Ho * Wo * (d.cout / 2)), d.name,
                         (double)nb * p.ty * p.tx * 4.0 * (6.0 * ((5 * L.dense + 3) / 4) * 3.0) * 2048.0);
@@ -979,8 +981,7 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
 // MFMA rate the layers are bound by the LDS fill, not by multiply-adds, so there is nothing for them to buy.)
 // two polyphase sub-images of 8 columns (and at most 8 rows) share one 8 x 16 raw tile (rconv16b_kernel, p.dual)
 static bool rconv16_dual_ok(const Layer& L, const LayerDef& d, int Hin, int Win) {
-  const char* e = getenv("SE_RCONV16_DUAL");             // (read per call: the tests compare both forms in one process)
-  if (e && atoi(e) == 0) return false;
+  if (opt(OPT_RCONV16_DUAL) == 0) return false;
   return rconv16_small_tiles() && L.d_w16s && (d.rate % 2) == 0 && Win / d.rate == 8 && Hin / d.rate <= 8 && Hin / d.rate >= 4;
 }
 
@@ -991,12 +992,11 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
   if ((C0 + C1) != L.CGp16 * 8) return fail(c, "layer %s: bf16 source channels %d+%d != packed %d", d.name, C0, C1, L.CGp16 * 8);
   // the dominant shape (96 -> 192, 3x3, stride 1) runs in the raw-tile form when its polyphase sub-images are large
   // enough to fill 16 x 16 tiles reasonably (se_rconv16.hip); SE_RCONV16=0 keeps it on the gather-GEMM
-  static const bool use_rconv = !(getenv("SE_RCONV16") && atoi(getenv("SE_RCONV16")) == 0);
+  const bool use_rconv = opt(OPT_RCONV16) != 0;
   // conv11 of netG: the spatially constant second source folded into a bias table (run_gconv / launch_vecbias), the layer on
   // the 8 x 16 raw-tile kernel with the first source alone
   {
-    const char* vb_env = getenv("SE_VECBIAS");
-    if (!(vb_env && atoi(vb_env) == 0) && use_rconv && !c->low_latency && src1 && src1_vec && c->vbias_ws && c->vec32 && L.d_w16s && L.d_wv16 &&
+    if (opt(OPT_VECBIAS) != 0 && use_rconv && !c->low_latency && src1 && src1_vec && c->vbias_ws && c->vec32 && L.d_w16s && L.d_wv16 &&
         rconv16_small_tiles() && d.k == 3 && d.stride == 1 && d.rate == 1 && !d.up && d.cin == 192 && d.cout == 192 && C0 == 96 && C1 == 96 &&
         Hin >= 12 && Win >= 12 && (long long)B * Hin * Win * 192 < (1ll << 31)) {
       HIPCHK(c, launch_vecbias(L.d_wv16, c->vec32, c->vbias_ws, B, 96, c->st, 1));
@@ -1030,7 +1030,7 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
     return 0;
   }
   // 96-row stride-1 layers (3x3 48/24 -> 96, gen_deconv 96 -> 96): raw-tile form, se_rconv96.hip (SE_RCONV96=0: gather-GEMM)
-  static const bool use_rconv96 = !(getenv("SE_RCONV96") && atoi(getenv("SE_RCONV96")) == 0);
+  const bool use_rconv96 = opt(OPT_RCONV96) != 0;
   if (use_rconv96 && !c->low_latency && L.d_w96 && !src1 && C0 == d.cin && Hin >= 12 && Win >= 12 &&
       (long long)B * Ho * Wo * 96 < (1ll << 31) && (long long)B * Hin * Win * C0 * 2 < (1ll << 31)) {
     RConv96Params rp;
@@ -1067,8 +1067,9 @@ int run_gconv16(se_ctx* c, const Layer& L, const float* src0, int C0, const floa
   for (int t = 0; t <= L.T + 8; ++t)
     if (((t * p.magicKW) >> 8) != t / KW) return fail(c, "layer %s: magic tap division check failed", d.name);
   const int Gs = (L.G + 7) & ~7;                 // stored channel stride of the output
-  if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) >= 2147483648.0 || (double)B * Ho * Wo * Gs >= 2147483648.0)
-    return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
+  // 32-bit byte offsets (sentinel 0x80000000): source and destination below 2^31 BYTES
+  if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) * 2.0 >= 2147483648.0 || (double)B * Ho * Wo * Gs * 2.0 >= 2147483648.0)
+    return fail(c, "layer %s: a tensor of this launch exceeds 2^31 bytes (32-bit byte offsets) -- split the batch", d.name);
   for (int j = 0; j < p.magicKH; ++j) p.rep |= 1u << (j * KW);
   udiv_magic_host((unsigned)(p.Ho * p.Wo), &p.div_hw_m, &p.div_hw_l);
   udiv_magic_host((unsigned)p.Wo, &p.div_w_m, &p.div_w_l);
@@ -1102,8 +1103,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   // Low-latency mode (SE_FLAG_LOW_LATENCY, one or two images): the Winograd kernels' 64/128-tile workgroups would
   // occupy 16-32 of the 256 CUs, so every gated conv takes the direct kernel in its small-grid shape instead
   // (launch_gconv: 64-pixel tiles, rows split over blockIdx.y).  2.25x more multiply-adds on ~10x more CUs.
-  static const bool use_wino_env = !(getenv("SE_WINOGRAD") && atoi(getenv("SE_WINOGRAD")) == 0);
-  const bool use_wino = use_wino_env && !c->low_latency;
+  const bool use_wino = opt(OPT_WINOGRAD) != 0 && !c->low_latency;
   const bool wino_src_ok = (!src1 && C0 == 96 && d.cin == 96) || (src1 && C0 == 96 && C1 == 96 && d.cin == 192);
   // the kernel addresses a source through 32-bit byte offsets (96 floats per pixel)
   const bool wino_addr_ok = (long long)B * Hin * Win * 384 < (1ll << 31);
@@ -1123,8 +1123,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     // A spatially constant second source is folded into a per-image, per-border-configuration bias (launch_vecbias) and
     // the layer runs as the SINGLE-source kernel: half the positions' K, 311 -> 170 us at 256x256 B=32 (SE_VECBIAS=0: the
     // two-source kernel reads the vector as a second input)
-    const char* vb_env = getenv("SE_VECBIAS");            // (read per call: the tests compare both forms in one process)
-    const bool vecbias_on = !(vb_env && atoi(vb_env) == 0);
+    const bool vecbias_on = opt(OPT_VECBIAS) != 0;
     bool folded = false;
     if (vecbias_on && src1 && src1_vec && d.rate == 1 && L.d_u1 && L.d_wv && c->vbias_ws && Hin >= 2 && Win >= 2) {
       HIPCHK(c, launch_vecbias(L.d_wv, src1, c->vbias_ws, B, 96, c->st));
@@ -1132,24 +1131,19 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
       folded = true;
     }
     // Hybrid F(2,3) x F(4,3) (se_wino24.hip) for the single-source form where the width allows 4-column tiles: 24 instead of
-    // 32 positions per 8 outputs.  SE_WINOGRAD_F43=0: F(2x2,3x3) everywhere; SE_WINOGRAD_F43=2: netG only (netM's soft mask
-    // feeds the 0.5 threshold).  Read per call: the tests compare both forms in one process.
-    const char* f43_env = getenv("SE_WINOGRAD_F43");
-    const int f43_mode = f43_env ? atoi(f43_env) : 1;
-    const char* f43_skip = getenv("SE_WINOGRAD_F43_SKIP");      // developer aid: comma-separated layer names that keep F(2x2,3x3)
-    bool skip_this = false;
-    if (f43_skip) {
-      std::string sk = std::string(",") + f43_skip + ",";
-      skip_this = sk.find(std::string(",") + d.name + ",") != std::string::npos;
-    }
-    const bool f43 = !skip_this && (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
+    // 32 positions per 8 outputs.  SE_WINOGRAD_F43=0: F(2x2,3x3) everywhere; 1: the hybrid kernel everywhere; 2: netG only;
+    // 3: everywhere except netM's mask decoder (conv_mask_11 / conv_mask_12: the last Winograd layers in front of the soft mask
+    // that feeds the 0.5 threshold, editline2_model.py:346-347).  DESIGN 3.1b' records the flip counts of each mode.
+    const int f43_mode = opt(OPT_WINOGRAD_F43);
+    const bool mask_tail = c->cur_net == SE_NET_M && !strncmp(d.name, "conv_mask_", 10);
+    const bool f43 = (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G) || (f43_mode == 3 && !mask_tail)) && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = f43 ? Win / 4 : Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
     udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
     udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
     udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
-    if ((double)B * Hin * Win * 96 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
+    if ((double)B * Hin * Win * 384.0 >= 2147483648.0) return fail(c, "layer %s: tensor exceeds 2^31 bytes", d.name);
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
     if (f43) {
       wp.upk = wp.src1 ? L.d_u24b : L.d_u24; wp.bias = L.d_ub24;
@@ -1165,9 +1159,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   }
   // 48 -> 192 (xconv5 of netG) on the hybrid kernel's 48-channel instantiation: 2 chunks per position, the second half empty
   {
-    const char* f43_env = getenv("SE_WINOGRAD_F43");
-    const int f43_mode = f43_env ? atoi(f43_env) : 1;
-    if (use_wino && f43_mode != 0 && !d.up && !src1 && C0 == 48 && d.cin == 48 && d.cout == 192 && d.stride == 1 && L.d_u24 && L.d_ub24 &&
+    if (use_wino && opt(OPT_WINOGRAD_F43) != 0 && !d.up && !src1 && C0 == 48 && d.cin == 48 && d.cout == 192 && d.stride == 1 && L.d_u24 && L.d_ub24 &&
         (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (4 * d.rate)) == 0) {
       WinoParams wp;
       memset(&wp, 0, sizeof wp);
@@ -1184,7 +1176,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
       return 0;
     }
   }
-  static const bool use_wino48 = !(getenv("SE_WINOGRAD48") && atoi(getenv("SE_WINOGRAD48")) == 0);
+  const bool use_wino48 = opt(OPT_WINOGRAD48) != 0;
   if (use_wino && use_wino48 && !d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && (long long)B * Hin * Win * 192 < (1ll << 31) &&
       (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
     WinoParams wp;
@@ -1201,7 +1193,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     HIPCHK(c, launch_wino48(wp, c->st));
     return 0;
   }
-  static const bool use_winoup = !(getenv("SE_WINOGRAD_UP") && atoi(getenv("SE_WINOGRAD_UP")) == 0);
+  const bool use_winoup = opt(OPT_WINOGRAD_UP) != 0;
   if (use_wino && use_winoup && d.up && L.d_u && L.d_ub && !src1 && C0 == 96 && d.cin == 96 &&
       (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0) {
     WinoParams wp;
@@ -1220,7 +1212,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     return 0;
   }
   // gen_deconv 48 -> 48: F(2x2,2x2) on the sub-pixel classes with the K pairing of the 48-channel kernels (se_wino_up48.hip)
-  static const bool use_winoup48 = !(getenv("SE_WINOGRAD_UP48") && atoi(getenv("SE_WINOGRAD_UP48")) == 0);
+  const bool use_winoup48 = opt(OPT_WINOGRAD_UP48) != 0;
   if (use_wino && use_winoup && use_winoup48 && d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && d.cout == 48 &&
       (long long)B * Hin * Win * 192 < (1ll << 31) && (long long)B * Ho * Wo * 96 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0) {
     WinoParams wp;
@@ -1256,8 +1248,9 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     if (((gi * p.magicCG) >> 16) != gi / L.CGp) return fail(c, "layer %s: magic division check failed", d.name);
   for (int t = 0; t <= L.T + 8; ++t)
     if (((t * p.magicKW) >> 8) != t / KW) return fail(c, "layer %s: magic tap division check failed", d.name);
-  if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) >= 2147483648.0 || (double)B * Ho * Wo * L.G >= 2147483648.0)
-    return fail(c, "layer %s: tensor exceeds 2^31 elements", d.name);
+  // 32-bit byte offsets (sentinel 0x80000000): source and destination below 2^31 BYTES
+  if ((double)B * Hin * Win * (C0 > C1 ? C0 : C1) * 4.0 >= 2147483648.0 || (double)B * Ho * Wo * L.G * 4.0 >= 2147483648.0)
+    return fail(c, "layer %s: a tensor of this launch exceeds 2^31 bytes (32-bit byte offsets) -- split the batch", d.name);
   p.ushift = 0;
   p.rep = 0;
   for (int j = 0; j < p.magicKH; ++j) p.rep |= 1u << (j * KW);
@@ -1591,6 +1584,25 @@ int check_dims(se_ctx* c, int B, int H, int W) {
   return 0;
 }
 
+// Passes of a forward over a large batch.  The kernels address a tensor with 32-bit byte offsets (addr_limit); the largest
+// tensor of either network is the 24-channel full-resolution activation (conv1 / conv15_upsample outputs: 96 bytes per
+// pixel in fp32, 48 in bf16), so a forward runs over at most (limit - 1) / (H W 96) images at a time and a larger batch is
+// run as several passes of the SAME plan over image ranges -- same kernels, same execution mode, so an image's result does
+// not depend on the pass it lands in (bit for bit: test_large_batch_is_split_into_passes).  Passes are balanced
+// (ceil(B / passes) images each).  Returns the images per pass, or 0 (error set) when ONE image exceeds the range.
+int pass_size(se_ctx* c, int B, int H, int W, int flags) {
+  const long long per_img = (long long)H * W * ((flags & SE_FLAG_BF16) ? 48 : 96);
+  const long long lim = addr_limit();
+  if (per_img >= lim) {
+    fail(c, "a %dx%d image exceeds the kernels' 32-bit byte offsets (%lld bytes per activation, limit %lld)", H, W, per_img, lim);
+    return 0;
+  }
+  const long long bmax = (lim - 1) / per_img;
+  if (B <= bmax) return B;
+  const long long passes = (B + bmax - 1) / bmax;
+  return (int)((B + passes - 1) / passes);
+}
+
 // Arena peaks of a forward, from a dry run of the very plan that will be launched (nothing is enqueued): main-branch
 // arena and, in low-latency mode, the side-branch arena.  which: 1 netM, 2 netG, 3 netM then netG (se_inference).
 se_ctx::Peaks plan_peaks(se_ctx* c, int which, int B, int H, int W, int flags, bool want_maskim) {
@@ -1637,6 +1649,7 @@ void begin_call(se_ctx* c, void* stream, int flags) {
   c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
   c->bf16 = (flags & SE_FLAG_BF16) != 0;
   c->rgb8 = nullptr; c->m8 = nullptr;
+  c->cur_net = SE_NET_G;       // per-op entry points run as netG layers whatever plan ran last; the plans set their own
   set_profiler(&c->prof);
 }
 
@@ -1795,11 +1808,17 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
         for (int bf = 0; bf < 2; ++bf) {      // (bf16 activations are smaller, but its attention scratch need not be)
           const int flags = (cam ? SE_FLAG_USE_CAM : 0) | (joint ? SE_FLAG_JOINT_TRAIN_INP : 0) | (ll ? SE_FLAG_LOW_LATENCY : 0) |
                             (bf ? SE_FLAG_BF16 : 0) | SE_FLAG_POOL_MAX;
+          // a batch beyond the kernels' 32-bit byte offsets runs as passes (pass_size): the workspace serves one pass at a time
+          const int nb = pass_size(c, B, H, W, flags);
+          if (!nb) return 0;
+          const int last = B % nb;                      // size of a ragged last pass (0: none)
           // with and without netM's image decoder (mode='visualize' vs 'inference'): two allocation sequences
-          for (int mi = 0; mi < 2; ++mi) {
-            const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, mi != 0);
-            if (pk.main + pk.side > peak) peak = pk.main + pk.side;
-          }
+          for (int mi = 0; mi < 2; ++mi)
+            for (int bb : {nb, last}) {
+              if (!bb) continue;
+              const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, mi != 0);
+              if (pk.main + pk.side > peak) peak = pk.main + pk.side;
+            }
         }
   return peak + 2 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes
 }
@@ -1812,9 +1831,18 @@ int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float*
   if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
   exec_flags &= SE_FLAG_LOW_LATENCY | SE_FLAG_BF16;
-  if (carve(c, plan_peaks(c, 1, B, H, W, exec_flags, maskim_out != nullptr), ws, ws_bytes, 0)) return 1;
-  begin_call(c, stream, exec_flags);
-  return plan_netM(c, image, sketch, mask_out, nullptr, maskim_out, B, H, W);
+  const int nb = pass_size(c, B, H, W, exec_flags);
+  if (!nb) return 1;
+  const size_t HW = (size_t)H * W;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    const int bb = std::min(nb, B - b0);
+    if (carve(c, plan_peaks(c, 1, bb, H, W, exec_flags, maskim_out != nullptr), ws, ws_bytes, 0)) return 1;
+    begin_call(c, stream, exec_flags);
+    const int rc = plan_netM(c, image + b0 * 3 * HW, sketch + b0 * HW, mask_out + b0 * HW, nullptr,
+                             maskim_out ? maskim_out + b0 * 3 * HW : nullptr, bb, H, W);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
@@ -1830,9 +1858,18 @@ int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, co
   if (check_dims(c, B, H, W)) return 1;
   if (!x || !x2 || !mask || !mask2 || !guide || !fine_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
-  if (carve(c, plan_peaks(c, 2, B, H, W, flags, false), ws, ws_bytes, 0)) return 1;
-  begin_call(c, stream, flags);
-  return plan_netG(c, x, x2, mask, mask2, guide, coarse_out, fine_out, nullptr, nullptr, B, H, W, flags);
+  const int nb = pass_size(c, B, H, W, flags);
+  if (!nb) return 1;
+  const size_t HW = (size_t)H * W;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    const int bb = std::min(nb, B - b0);
+    if (carve(c, plan_peaks(c, 2, bb, H, W, flags, false), ws, ws_bytes, 0)) return 1;
+    begin_call(c, stream, flags);
+    const int rc = plan_netG(c, x + b0 * 3 * HW, x2 + b0 * 3 * HW, mask + b0 * HW, mask2 + b0 * HW, guide + b0 * HW,
+                             coarse_out ? coarse_out + b0 * 3 * HW : nullptr, fine_out + b0 * 3 * HW, nullptr, nullptr, bb, H, W, flags);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 namespace {
@@ -1842,19 +1879,31 @@ int enqueue_inference(se_ctx* c, void* stream, const float* image, const float* 
                       int B, int H, int W, int flags) {
   // the hard mask lives at the end of the workspace for the whole call
   const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
-  const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, maskim_out != nullptr);
-  if (carve(c, pk, ws, ws_bytes, plane)) return 1;
-  float* hard = hard_out ? hard_out : (float*)((char*)ws + ws_bytes - plane);
+  float* hard_all = hard_out ? hard_out : (float*)((char*)ws + ws_bytes - plane);
   // SE_FLAG_PACKED_OUT: composed_out is one (B,4,H,W) buffer, planes 0-2 the composite, plane 3 the soft mask
+  const size_t HW = (size_t)H * W;
   const long packed_bs = (flags & SE_FLAG_PACKED_OUT) ? 4l * H * W : 0;
-  if (packed_bs) mask_out = composed_out + 3l * H * W;
-  begin_call(c, stream, flags);
-  int rc = plan_netM(c, image, sketch, mask_out, hard, maskim_out, B, H, W, packed_bs);     // editline2_model.py:339,346-347
-  if (rc) return rc;
-  if (carve(c, pk, ws, ws_bytes, plane)) return 1;
-  // netG(inputs, inputs, mask_inpaint, mask_inpaint, line)  :366-368 ; composite with the soft mask :132
-  return plan_netG(c, image, image, hard, hard, sketch, coarse_out, fine_out, mask_out, composed_out, B, H, W, flags,
-                   packed_bs);
+  if (packed_bs) mask_out = composed_out + 3 * HW;
+  const size_t comp_bs = packed_bs ? (size_t)packed_bs : 3 * HW, mask_bs = packed_bs ? (size_t)packed_bs : HW;
+  // a batch beyond the kernels' 32-bit byte offsets runs as passes over image ranges (pass_size)
+  const int nb = pass_size(c, B, H, W, flags);
+  if (!nb) return 1;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    const int bb = std::min(nb, B - b0);
+    const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, maskim_out != nullptr);
+    if (carve(c, pk, ws, ws_bytes, plane)) return 1;
+    const float *img = image + b0 * 3 * HW, *sk = sketch + b0 * HW;
+    float *hard = hard_all + b0 * HW, *mk = mask_out + b0 * mask_bs;
+    begin_call(c, stream, flags);
+    int rc = plan_netM(c, img, sk, mk, hard, maskim_out ? maskim_out + b0 * 3 * HW : nullptr, bb, H, W, packed_bs);     // editline2_model.py:339,346-347
+    if (rc) return rc;
+    if (carve(c, pk, ws, ws_bytes, plane)) return 1;
+    // netG(inputs, inputs, mask_inpaint, mask_inpaint, line)  :366-368 ; composite with the soft mask :132
+    rc = plan_netG(c, img, img, hard, hard, sk, coarse_out ? coarse_out + b0 * 3 * HW : nullptr, fine_out ? fine_out + b0 * 3 * HW : nullptr,
+                   mk, composed_out + b0 * comp_bs, bb, H, W, flags, packed_bs);
+    if (rc) return rc;
+  }
+  return 0;
 }
 }  // namespace
 
@@ -1921,16 +1970,26 @@ int se_inference_u8(se_ctx* c, void* stream, const float* image, const float* sk
   HIPCHK(c, hipSetDevice(c->device));
   flags &= ~(SE_FLAG_GRAPH | SE_FLAG_PACKED_OUT);
   const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
-  const se_ctx::Peaks pk = plan_peaks(c, 3, B, H, W, flags, false);
-  if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
-  float* hard = (float*)((char*)ws + ws_bytes - plane);
-  float* soft = (float*)((char*)ws + ws_bytes - 2 * plane);
-  begin_call(c, stream, flags);
-  int rc = plan_netM(c, image, sketch, soft, hard, nullptr, B, H, W);
-  if (rc) return rc;
-  if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
-  c->rgb8 = rgb_out; c->m8 = mask_u8_out;
-  return plan_netG(c, image, image, hard, hard, sketch, nullptr, nullptr, soft, nullptr, B, H, W, flags);
+  float* hard_all = (float*)((char*)ws + ws_bytes - plane);
+  float* soft_all = (float*)((char*)ws + ws_bytes - 2 * plane);
+  const size_t HW = (size_t)H * W;
+  const int nb = pass_size(c, B, H, W, flags);       // passes over image ranges beyond the kernels' 32-bit byte offsets
+  if (!nb) return 1;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    const int bb = std::min(nb, B - b0);
+    const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, false);
+    if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
+    const float *img = image + b0 * 3 * HW, *sk = sketch + b0 * HW;
+    float *hard = hard_all + b0 * HW, *soft = soft_all + b0 * HW;
+    begin_call(c, stream, flags);
+    int rc = plan_netM(c, img, sk, soft, hard, nullptr, bb, H, W);
+    if (rc) return rc;
+    if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
+    c->rgb8 = rgb_out + b0 * 3 * HW; c->m8 = mask_u8_out ? mask_u8_out + b0 * HW : nullptr;
+    rc = plan_netG(c, img, img, hard, hard, sk, nullptr, nullptr, soft, nullptr, bb, H, W, flags);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 // test.py:25-27 on the device
@@ -2009,6 +2068,11 @@ int se_profile_report(se_ctx* c, char* buf, size_t cap) {
   memcpy(buf, s.c_str(), s.size() + 1);
   return 0;
 }
+
+// ---- developer switches (se_kernels.h SE_OPTIONS): process-wide, read from the environment once ----
+int se_debug_set_option(const char* name, int value) { return opt_set(name, value); }
+int se_debug_get_option(const char* name, int* value) { return opt_get(name, value); }
+void se_debug_reset_options(void) { opt_reset(); }
 
 // ---- unit-test entry points (allocate scratch internally; synchronise the stream before freeing) ----
 int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1, int x1_is_vector, const float* w_host,

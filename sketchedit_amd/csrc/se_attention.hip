@@ -644,7 +644,11 @@ __global__ __launch_bounds__(256) void att2_pair_kernel(const AttParams p) {
       if (BF16 && p.e16) {          // E in fp16 (bf16 mode with the LDS-staged fused passes): 8 bytes per lane
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const h4 hv = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};      // (already centred: accumulator start)
+        // (already centred: accumulator start.)  Saturated to the fp16 range: a centred score beyond +-65504 would
+        // become inf and the LDS-staged passes would form inf - inf = NaN for the whole row; clamped, such an entry still
+        // dominates (or vanishes from) its softmax row exactly as before -- 2^(10 * 65504 * log2 e) is out of range either way.
+        auto sat = [](float t) { return __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f); };
+        const h4 hv = (h4){(_Float16)sat(v[0]), (_Float16)sat(v[1]), (_Float16)sat(v[2]), (_Float16)sat(v[3])};
         __builtin_nontemporal_store(__builtin_bit_cast(u32x2, hv), (u32x2*)((char*)p.E + (((size_t)b * p.R + i) * p.Rp + j) * 2));
       } else __builtin_nontemporal_store(v, (f32x4*)(p.E + ((size_t)b * p.R + i) * p.Rp + j));
     }
@@ -1544,19 +1548,17 @@ __global__ void att2_similar_kernel(const AttParams p) {
 // Default: fused wherever the LDS-staged kernels apply (wc % 4 == 0, wc <= 124), in fp32 also for R <= 1024 (round-3 kernels).
 // SE_ATT_FUSED=0 / 1 forces the three-pass / fused form (in bf16 mode together with SE_ATT_FUSED_BF16=1); SE_ATT_FUSED_BF16=0
 // keeps bf16 mode on the three-pass form; SE_ATT_PTILDE_LDS=0 keeps the round-3 streaming kernels inside the fused form;
-// SE_ATT_STATS_LDS=0 the round-3 statistics kernel; SE_ATT_E16=0 fp32 E in bf16 mode.  (Read per call, not cached: the tests
-// switch forms inside one process.)
+// SE_ATT_STATS_LDS=0 the round-3 statistics kernel; SE_ATT_E16=0 fp32 E in bf16 mode.  (Entries of the option table,
+// se_kernels.h: the tests switch forms inside one process through se_debug_set_option; -1 = not set.)
 static bool att_lds_form(int wc) {
-  const char* e = getenv("SE_ATT_PTILDE_LDS");
-  return wc % 4 == 0 && wc <= 124 && !(e && atoi(e) == 0);
+  return wc % 4 == 0 && wc <= 124 && opt(OPT_ATT_PTILDE_LDS) != 0;
 }
 static bool att_fused(bool bf16, int Rp, int wc) {
-  const char* e1 = getenv("SE_ATT_FUSED");
-  const char* e2 = getenv("SE_ATT_FUSED_BF16");
-  const int f32mode = e1 ? (atoi(e1) != 0 ? 1 : 0) : -1;
+  const int e1 = opt(OPT_ATT_FUSED), e2 = opt(OPT_ATT_FUSED_BF16);
+  const int f32mode = e1 < 0 ? -1 : (e1 != 0 ? 1 : 0);
   if (bf16) {
-    if (e2 && atoi(e2) == 0) return false;
-    if (e2) return f32mode < 0 ? att_lds_form(wc) : f32mode == 1;      // (explicitly enabled: SE_ATT_FUSED decides, as in fp32)
+    if (e2 == 0) return false;
+    if (e2 > 0) return f32mode < 0 ? att_lds_form(wc) : f32mode == 1;      // (explicitly enabled: SE_ATT_FUSED decides, as in fp32)
     return f32mode != 0 && att_lds_form(wc);
   }
   return f32mode < 0 ? (Rp <= 1024 || att_lds_form(wc)) : f32mode == 1;
@@ -1569,9 +1571,9 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
   p.Pt = fused ? p.P : p.E;
   // SE_ATT_STATS_LDS=0: att2_stats_kernel instead of the LDS-staged statistics pass.  SE_ATT_E16=0: E stays fp32 in bf16 mode
   // (fp16 E needs both LDS-staged kernels: they are the only readers that convert).
-  p.sym = (!BF16 && !(getenv("SE_ATT_SYM") && atoi(getenv("SE_ATT_SYM")) == 0)) ? 1 : 0;      // SE_ATT_SYM=0: every tile of E computed, from x and xn = x rn
-  const bool stats_lds = !(getenv("SE_ATT_STATS_LDS") && atoi(getenv("SE_ATT_STATS_LDS")) == 0);
-  p.e16 = (BF16 && fused && att_lds_form(p.wc) && stats_lds && !(getenv("SE_ATT_E16") && atoi(getenv("SE_ATT_E16")) == 0)) ? 1 : 0;
+  p.sym = (!BF16 && opt(OPT_ATT_SYM) != 0) ? 1 : 0;      // SE_ATT_SYM=0: every tile of E computed, from x and xn = x rn
+  const bool stats_lds = opt(OPT_ATT_STATS_LDS) != 0;
+  p.e16 = (BF16 && fused && att_lds_form(p.wc) && stats_lds && opt(OPT_ATT_E16) != 0) ? 1 : 0;
   {
     const long n = (long)p.B * p.h * p.w * (BF16 ? 12 : 24);
     // Preconditions of the fused streaming pass: its column shifts read up to wc + 8 floats in front of / behind
@@ -1707,7 +1709,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     // pixel tile of the large-batch form, chosen on the GPU (SE_ATT_PV_PT overrides): 256 pixels (PT = 4) need 88 KB of LDS --
     // ONE workgroup per CU; 128 (fp32) / 192 (bf16) fit two, whose barrier and DMA waits overlap: fp32 784 -> 747 us at
     // 512x512 B=8, bf16 307 -> 247 us at 512x512 B=16 (same box, round 3)
-    static const int pvpt = getenv("SE_ATT_PV_PT") ? atoi(getenv("SE_ATT_PV_PT")) : (BF16 ? 3 : 2);
+    const int pvpt = opt(OPT_ATT_PV_PT) > 0 ? opt(OPT_ATT_PV_PT) : (BF16 ? 3 : 2);
     if (big_grid >= 512 && pvpt == 4) {
       constexpr int PT = 4, NT = 6;
       constexpr int LDS = 2 * PT * 64 * 128 + 2 * NT * 16 * 128;
@@ -1757,8 +1759,7 @@ hipError_t launch_attention(const AttParams& p, hipStream_t st) {
   return p.E ? launch_attention_v2(p, st) : launch_attention_v1(p, st);
 }
 bool attention_v2_enabled() {
-  static const bool v1 = getenv("SE_ATT_V1") && atoi(getenv("SE_ATT_V1")) != 0;
-  return !v1;
+  return opt(OPT_ATT_V1) == 0;
 }
 
 }  // namespace se

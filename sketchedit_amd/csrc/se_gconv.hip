@@ -340,8 +340,7 @@ static hipError_t launch_gconv_f(const GConvParams& p, hipStream_t st, int label
 
 // the buffer-resource fast path needs one source, <= 31 taps and a source below 2 GiB (32-bit byte offsets)
 static bool fast_eligible(const GConvParams& p) {
-  static const bool enabled = !(getenv("SE_GCONV_FAST") && atoi(getenv("SE_GCONV_FAST")) == 0);
-  return enabled && p.C0g == p.CG && !p.ushift && p.T <= 31 && p.magicKH * p.KW == p.T &&
+  return opt(OPT_GCONV_FAST) != 0 && p.C0g == p.CG && !p.ushift && p.T <= 31 && p.magicKH * p.KW == p.T &&
          (long long)p.B * p.Hin * p.Win * p.C0 * (p.bf16 ? 2 : 4) < (1ll << 31);
 }
 template <int NT, int PT, bool MIXED, int WPS, bool SPLIT = false, int STAGES = 2>
@@ -359,14 +358,8 @@ static hipError_t launch_gconv_t(const GConvParams& p, hipStream_t st, int label
 // tuning sweeps.  Shapes with LDS <= 80 KiB and <= 256 registers run two workgroups per CU, so the staging
 // code, LDS-read latency and epilogue of one overlap the MFMAs of the other.
 static int variant_of(int cfg) {
-  static int v[4] = {-1, -1, -1, -1};
-  if (v[cfg] < 0) {
-    static const char* names[4] = {"SE_GCONV_VARIANT_N192", "SE_GCONV_VARIANT_N96", "SE_GCONV_VARIANT_N48",
-                                   "SE_GCONV_VARIANT_N24"};
-    const char* e = getenv(names[cfg]);
-    v[cfg] = e ? atoi(e) : 0;
-  }
-  return v[cfg];
+  static const int o[4] = {OPT_GCONV_VARIANT_N192, OPT_GCONV_VARIANT_N96, OPT_GCONV_VARIANT_N48, OPT_GCONV_VARIANT_N24};
+  return opt(o[cfg]);
 }
 
 hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
@@ -376,7 +369,7 @@ hipError_t launch_gconv(int cfg, const GConvParams& p, hipStream_t st) {
     // SE_LL_STAGES=4 (developer switch) runs them on the 4-slot ring with a counted vmcnt instead of double buffering.
     // Measured (1 image): 256x256 1.327 -> 1.313 ms, 512x512 3.75 -> 4.08 ms (48 KB of LDS per workgroup cost more
     // residency than the deeper prefetch returns; per chunk the ~0.8 us are barrier + issue overhead, not DMA latency).
-    static const int stages = getenv("SE_LL_STAGES") ? atoi(getenv("SE_LL_STAGES")) : 2;
+    const int stages = opt(OPT_LL_STAGES);
     if (stages == 2) {
       switch (cfg) {
         case GC_N192: return launch_gconv_t<2, 1, false, 4, true>(p, st, PL_GCONV_N192);

@@ -34,6 +34,39 @@ void set_launch_grid(long blocks);
 hipError_t ensure_max_lds(const void* func, int bytes);
 
 // ---------------------------------------------------------------------------------------------
+// Developer switches.  ONE process-wide table: every entry is read from the environment exactly once (first use of the
+// table) and can afterwards be changed only through the C-ABI test aid se_debug_set_option -- the launch path never calls
+// getenv (ADVICE r4 / VERDICT r4 item 7c: getenv per launch is host latency at batch 1 and is not safe against a concurrent
+// setenv from another thread).  opt() is a relaxed atomic load.
+// ---------------------------------------------------------------------------------------------
+#define SE_OPTIONS(X)                                                                                         \
+  X(XCD_REMAP, 1)        /* 0: XCD-aware tile order off */                                                     \
+  X(RTILE, 1)            /* 0: gather-GEMM instead of the raw-tile kernels */                                  \
+  X(RTILE_LL_MIN, 256)   /* low-latency mode: fewest raw tiles for which the raw-tile kernels still run */      \
+  X(RTILE_WX, 2)         /* 24 -> 24 layers: 0 direct raw tile, 1 F(2,3) along x, 2 two-dimensional F(2x2,3x3) */ \
+  X(RTILE_DENSE, 1)      /* 0: channel-padded K for the 5x5 first layers */                                    \
+  X(RTILE_D5W, 1)        /* 0: 5x5 first layers on the direct dense-K kernel */                                \
+  X(TEST_OFFSET_LIMIT, 0) /* test aid, se_debug_set_option only: byte range of the 32-bit-offset kernels (0: 2^31) */ \
+  X(RCONV16, 1) X(RCONV16_DUAL, 1) X(RCONV16_TILE, 8) X(RCONV96, 1) X(VECBIAS, 1)                              \
+  X(WINOGRAD, 1) X(WINOGRAD48, 1) X(WINOGRAD_UP, 1) X(WINOGRAD_UP48, 1)                                         \
+  X(WINOGRAD_F43, 1)     /* hybrid F(2,3)xF(4,3): 0 off, 1 everywhere, 2 netG only, 3 everywhere but netM's mask decoder */ \
+  X(WINO48_TILES, 64) X(WINOUP_TILES, 64)                                                                       \
+  X(GCONV_FAST, 1) X(GCONV_VARIANT_N192, 0) X(GCONV_VARIANT_N96, 0) X(GCONV_VARIANT_N48, 0) X(GCONV_VARIANT_N24, 0) \
+  X(LL_STAGES, 2)                                                                                               \
+  X(ATT_V1, 0) X(ATT_FUSED, -1) X(ATT_FUSED_BF16, -1) X(ATT_PTILDE_LDS, 1) X(ATT_STATS_LDS, 1) X(ATT_E16, 1)      \
+  X(ATT_SYM, 1) X(ATT_PV_PT, -1)
+enum Opt {
+#define X(name, dflt) OPT_##name,
+  SE_OPTIONS(X)
+#undef X
+  OPT_COUNT
+};
+int opt(int o);                                   // current value
+int opt_set(const char* name, int value);         // "SE_<NAME>" or "<NAME>"; returns 0, or 1 for an unknown name
+int opt_get(const char* name, int* value);        // the same for reading
+void opt_reset();                                 // every entry back to its environment / built-in default
+
+// ---------------------------------------------------------------------------------------------
 // Gather-GEMM gated convolution (the hot kernel).
 //   D[n][p] = sum_k Wp[n][k] * X[p][k]   n: packed output channels, p: output pixels,
 //   k: flattened (tap, channel) in 32-float chunks.  X rows are gathered on the fly from

@@ -4,11 +4,73 @@
 // host-side launch profiler.
 #include "se_device.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <set>
 #include <utility>
 
 namespace se {
+
+// ---- developer switches (se_kernels.h SE_OPTIONS) ---------------------------------------------------
+namespace {
+struct OptTable {
+  std::atomic<int> v[OPT_COUNT];
+  int dflt[OPT_COUNT];
+  OptTable() { load(); }
+  void load() {
+    static const char* names[OPT_COUNT] = {
+#define X(name, d) "SE_" #name,
+        SE_OPTIONS(X)
+#undef X
+    };
+    static const int builtin[OPT_COUNT] = {
+#define X(name, d) d,
+        SE_OPTIONS(X)
+#undef X
+    };
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      const char* e = i == OPT_TEST_OFFSET_LIMIT ? nullptr : getenv(names[i]);      // (the test aid is not an environment switch)
+      dflt[i] = e ? atoi(e) : builtin[i];
+      v[i].store(dflt[i], std::memory_order_relaxed);
+    }
+  }
+  static int index_of(const char* name) {
+    static const char* names[OPT_COUNT] = {
+#define X(name, d) #name,
+        SE_OPTIONS(X)
+#undef X
+    };
+    if (!name) return -1;
+    if (!strncmp(name, "SE_", 3)) name += 3;
+    for (int i = 0; i < OPT_COUNT; ++i)
+      if (!strcmp(name, names[i])) return i;
+    return -1;
+  }
+};
+OptTable& opt_table() {
+  static OptTable t;      // C++11: initialised once, thread-safe -- the only getenv calls of the library's launch path
+  return t;
+}
+}  // namespace
+int opt(int o) { return opt_table().v[o].load(std::memory_order_relaxed); }
+int opt_set(const char* name, int value) {
+  const int i = OptTable::index_of(name);
+  if (i < 0) return 1;
+  opt_table().v[i].store(value, std::memory_order_relaxed);
+  return 0;
+}
+int opt_get(const char* name, int* value) {
+  const int i = OptTable::index_of(name);
+  if (i < 0) return 1;
+  if (value) *value = opt(i);
+  return 0;
+}
+void opt_reset() {
+  OptTable& t = opt_table();
+  for (int i = 0; i < OPT_COUNT; ++i) t.v[i].store(t.dflt[i], std::memory_order_relaxed);
+}
 
 // ---- profiler plumbing ----------------------------------------------------------------------------
 static thread_local Profiler* g_prof = nullptr;

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
 }
 
 bool rconv16_small_tiles() {
-  static const bool big = getenv("SE_RCONV16_TILE") && atoi(getenv("SE_RCONV16_TILE")) == 16;
+  const bool big = opt(OPT_RCONV16_TILE) == 16;
   return !big;
 }
 

@@ -360,7 +360,7 @@ static hipError_t launch_wino48_t(const WinoParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
-  static const bool big = W48_TRACE_LDS || (getenv("SE_WINO48_TILES") && atoi(getenv("SE_WINO48_TILES")) == 128);
+  const bool big = W48_TRACE_LDS || opt(OPT_WINO48_TILES) == 128;
   return big ? launch_wino48_t<128>(p, st) : launch_wino48_t<64>(p, st);
 }
 

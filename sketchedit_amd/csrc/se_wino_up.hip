@@ -294,7 +294,7 @@ static hipError_t launch_winoup_t(const WinoParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_winoup(const WinoParams& p, hipStream_t st) {
-  static const bool big = getenv("SE_WINOUP_TILES") && atoi(getenv("SE_WINOUP_TILES")) == 128;
+  const bool big = opt(OPT_WINOUP_TILES) == 128;
   return big ? launch_winoup_t<128>(p, st) : launch_winoup_t<64>(p, st);
 }
 

@@ -69,16 +69,19 @@ class EditLine2Model(torch.nn.Module):
         return data["image"], data["gt"], data["mask"], data["edgegt"], None
 
     def _mode_for(self, B, H, W, low_latency):
-        """Execution mode of a call of B images when the caller did not pin it: the mode a FULL batch (--batchSize) of this
-        size would take.  test.py --batchSize 8 over 20 files runs batches of 8, 8, 4; chosen from the call's own size the
-        last one would cross LOW_LATENCY_MAX_PIXELS into the other mode (other kernels: fp32-rounding differences, possibly
-        another hard-mask pixel) -- an image's result must not depend on where the file list ends."""
-        if low_latency is not None:
-            return bool(low_latency)
-        full = max(int(B), int(getattr(self.opt, "batchSize", 1) or 1))
-        return _lib.Engine.is_low_latency(full, H, W)
+        """Execution mode of a call of B images: the caller's pin, else by the call's OWN size (an interactive caller that
+        configured --batchSize 8 and sends single images keeps the low-latency kernels)."""
+        return _lib.Engine.is_low_latency(int(B), H, W, low_latency)
 
-    def inference_u8(self, data):
+    def batch_mode(self, H, W):
+        """The mode a FULL --batchSize batch of H x W images takes -- what a batching loop pins for every batch of its file
+        list.  test.py --batchSize 8 over 20 files runs batches of 8, 8, 4: chosen from each call's own size the last one
+        would cross LOW_LATENCY_MAX_PIXELS into the other mode (other kernels: fp32-rounding differences, possibly another
+        hard-mask pixel) -- an image's PNG must not depend on where the file list ends, so test.py passes
+        `low_latency=model.batch_mode(H, W)`."""
+        return _lib.Engine.is_low_latency(int(getattr(self.opt, "batchSize", 1) or 1), H, W)
+
+    def inference_u8(self, data, low_latency=None):
         """mode='inference' followed by test.py:25-27 -- `((generated + 1) / 2 * 255).astype(uint8)` in HWC order and
         `(mask * 255).astype(uint8)` -- as ONE library call: the quantisation is fused into the forward's last kernel, so
         only uint8 leaves the device.  -> (rgb (B,H,W,3) uint8, mask (B,H,W) uint8), both on the device."""
@@ -88,13 +91,12 @@ class EditLine2Model(torch.nn.Module):
         eng = self.engine()
         with torch.no_grad():
             return eng.inference_u8(inputs.float().contiguous(), line.float().contiguous(), _lib.flags_from_opt(self.opt),
-                                    low_latency=self._mode_for(inputs.shape[0], inputs.shape[2], inputs.shape[3], None))
+                                    low_latency=self._mode_for(inputs.shape[0], inputs.shape[2], inputs.shape[3], low_latency))
 
     def forward(self, data, mode, low_latency=None):
-        """`low_latency` (no reference counterpart): None = the execution mode of a full --batchSize batch of this image size
-        (_mode_for: a ragged last batch runs in the mode of the full ones), True / False = pinned.  Results are bit-identical across batch compositions only WITHIN one mode
-        (include/sketchedit_hip.h), so callers whose batch size varies per request (serve.BatchingServer,
-        shard.sharded_inference) pin it."""
+        """`low_latency` (no reference counterpart): None = by this call's own size, True / False = pinned.  Results are
+        bit-identical across batch compositions only WITHIN one mode (include/sketchedit_hip.h), so callers whose batch size
+        varies per request (serve.BatchingServer, shard.sharded_inference, test.py's loop through batch_mode) pin it."""
         inputs, real_image, line, line_full, _ = self.preprocess_input(data)
         if mode not in ("inference", "visualize"):
             raise ValueError("|mode| is invalid")

@@ -42,7 +42,9 @@ def main(argv=None):
             break
         # mode='inference' with (x+1)/2*255 and mask*255 -> uint8 (no clamp, as test.py:26-27) fused into the forward's
         # last kernel, already HWC: nothing but uint8 is written or copied to the host
-        rgb, m8 = model.inference_u8(data_i)
+        # every batch of the list, the ragged last one included, in the execution mode of a FULL --batchSize batch
+        H, W = data_i["image"].shape[2:]
+        rgb, m8 = model.inference_u8(data_i, low_latency=model.batch_mode(H, W))
         generated, mask = rgb.cpu().numpy(), m8.cpu().numpy()
         for b in range(generated.shape[0]):
             path = data_i["path"][b]

@@ -326,7 +326,7 @@ def test_test_celeb_sh_with_checkpoint_files_on_disk(tmp_path, golden_dir):
 
     _run_test_py((base + " --batchSize 1 --output_dir {d}/results".format(d=tmp_path)).split())       # test_celeb.sh: batch 1
     check(tmp_path / "results")
-    # a ragged last batch runs in the execution mode of the FULL batches (EditLine2Model._mode_for): --batchSize 5 puts five
+    # a ragged last batch runs in the execution mode of the FULL batches (test.py pins EditLine2Model.batch_mode): --batchSize 5 puts five
     # 256x256 images above LOW_LATENCY_MAX_PIXELS (default mode); a file list that ends with a batch of two stays in that
     # mode, so a file's PNG is byte-identical wherever the list ends
     shutil.copy(tmp_path / "images" / "602.png", tmp_path / "images" / "602b.png")

@@ -368,14 +368,18 @@ def test_execution_mode_is_pinned_where_batch_composition_varies():
     shard.sharded_inference(fwd, torch.zeros(4, 3, 256, 256), torch.zeros(4, 1, 256, 256))
     assert seen == [False, True]
     assert shard.global_mode(8, 256, 256) is False and shard.global_mode(1, 512, 512) is True
-    # EditLine2Model (test.py): the mode of a FULL --batchSize batch, so a ragged last batch does not change kernels
+    # EditLine2Model: a call's own size picks the mode unless pinned (an interactive caller with --batchSize 8 that sends one
+    # image keeps the low-latency kernels); test.py pins the mode of a FULL --batchSize batch for its whole file
+    # list (batch_mode), so a ragged last batch does not change kernels
     from types import SimpleNamespace
     from sketchedit_amd.models.editline2_model import EditLine2Model
-    mf = EditLine2Model._mode_for
-    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=8)), 4, 256, 256, None) is False      # 8, 8, 4: all default mode
-    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=1)), 1, 256, 256, None) is True       # test_celeb.sh
-    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=1)), 32, 256, 256, None) is False     # a caller's own big batch
-    assert mf(SimpleNamespace(opt=SimpleNamespace(batchSize=8)), 4, 256, 256, True) is True       # pinned wins
+    mf, bm = EditLine2Model._mode_for, EditLine2Model.batch_mode
+    m8, m1 = SimpleNamespace(opt=SimpleNamespace(batchSize=8)), SimpleNamespace(opt=SimpleNamespace(batchSize=1))
+    assert mf(m8, 1, 256, 256, None) is True and mf(m8, 8, 256, 256, None) is False               # by the call's own size
+    assert mf(m1, 32, 256, 256, None) is False                                                    # a caller's own big batch
+    assert mf(m8, 4, 256, 256, True) is True and mf(m1, 1, 256, 256, False) is False              # pinned wins
+    assert bm(m8, 256, 256) is False and mf(m8, 4, 256, 256, bm(m8, 256, 256)) is False           # test.py: 8, 8, 4 all default mode
+    assert bm(m1, 256, 256) is True                                                               # test_celeb.sh
 
 
 def test_check_checkpoint_missing_key_not_hidden_by_suffix_match(tmp_path):
