@@ -93,12 +93,58 @@ def cpu_baseline(budget_s=25.0):
             O.inference(WM, WG, img, sk)
             times.append(time.perf_counter() - t0)
         samples.append({"size": size, "batch": B, "images_per_sec": B / float(np.median(times)), "runs": len(times)})
+    all_cores = cpu_all_cores_sample(host) if host > cores else {"threads": host, "images_per_sec": samples[1]["images_per_sec"], "note": "same as samples[1]: the host has no more than 32 CPUs"}
     return {"value": samples[0]["images_per_sec"], "unit": "images/sec", "cores": cores, "host_cores": host,
-            "thread_cap": 32, "kind": "port",
+            "thread_cap": 32, "kind": "port", "all_cores": all_cores,
             "sample": "oracle (torch CPU restatement of the reference): value = 256x256 batch 8, median of %d runs after 2 "
                       "warm-ups; `samples` also holds 256x256 batch 1 and 512x512 batch 1 (%.0f s of CPU work in all)"
                       % (samples[0]["runs"], time.perf_counter() - t_all),
             "samples": samples}
+
+
+def cpu_all_cores_probe():
+    """Child mode of cpu_all_cores_sample: the oracle at 256x256 batch 1 on EVERY host CPU, one line per finished forward."""
+    from oracle import sketchedit_oracle as O
+    host = os.cpu_count() or 1
+    torch.set_num_threads(host)
+    WM = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()}
+    WG = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()}
+    img, sk = synth.make_inputs(1, 256, 256, seed=1234)
+    img, sk = torch.from_numpy(img), torch.from_numpy(sk)
+    for i in range(4):                                    # run 0 is the warm-up
+        t0 = time.perf_counter()
+        O.inference(WM, WG, img, sk)
+        print(json.dumps({"run": i, "seconds": time.perf_counter() - t0, "threads": torch.get_num_threads()}), flush=True)
+
+
+def cpu_all_cores_sample(host, budget_s=40.0):
+    """SURVEY.md 8d asks for the CPU path on ALL host cores with the count printed; `value` keeps the 32-thread figure because
+    oneDNN collapses when oversubscribed on the GPU hosts (tools/cpu_probe.py: 256 threads 0.03 img/s).  This leg puts the
+    all-cores number on the line too, bounded: a child process runs 256x256 batch 1 forwards with torch.set_num_threads(host)
+    and is stopped after `budget_s` seconds; whatever finished is reported (the first forward is the warm-up)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-all-cores-probe"]
+    runs = []
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, 9)
+            out, _ = p.communicate()
+        for ln in out.decode().splitlines():
+            if ln.startswith("{"):
+                runs.append(json.loads(ln))
+    except (OSError, ValueError) as e:
+        return {"threads": host, "images_per_sec": None, "note": "probe failed: %r" % (e,)}
+    timed = [r["seconds"] for r in runs if r["run"] > 0]
+    if timed:
+        return {"threads": host, "images_per_sec": 1.0 / float(np.median(timed)), "runs": len(timed), "size": 256, "batch": 1,
+                "note": "oracle with torch.set_num_threads(all %d host CPUs), median after one warm-up, stopped after %.0f s" % (host, budget_s)}
+    if runs:
+        return {"threads": host, "images_per_sec": 1.0 / runs[0]["seconds"], "runs": 0, "size": 256, "batch": 1,
+                "note": "only the warm-up forward finished within %.0f s on all %d host CPUs (oversubscribed oneDNN): its own time" % (budget_s, host)}
+    return {"threads": host, "images_per_sec": None, "runs": 0, "size": 256, "batch": 1,
+            "note": "no 256x256 forward finished within %.0f s on all %d host CPUs (oversubscribed oneDNN); < %.3f images/sec" % (budget_s, host, 1.0 / budget_s)}
 
 
 TRACE_US = {}      # label -> {"avg_us", "launches"} from the rocprofv3 --kernel-trace child pass (filled by pmc_traffic)
@@ -349,13 +395,20 @@ def secondary_config(dev_index, size, batch, dtype, steps=12, warmup=3):
     return {"config": "%dx%d batch %d %s, 1 GPU" % (size, size, batch, "fp32" if dtype == "f32" else "bf16 MFMA, fp32 accumulate"),
             "dtype": dtype, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 4), "value": round(batch * steps / elapsed, 2),
             "unit": "images/sec",
-            "roofline": {"kernel": dom["kernel"], "frac": round(dom["flops_executed"] / (dom["total_ms"] * 1e-3) / 1e12 / peak, 4), "peak": peak,
-                         "forward_executed_frac": round(mf_ex / (mf_ms * 1e-3) / 1e12 / peak, 4), "attention_ms": round(att_ms, 4)},
+            # the headline's two conventions: frac = EXECUTED multiply-adds / peak (<= 1), frac_algorithmic = reference-defined
+            # FLOPs / peak (above 1 where a Winograd / sub-pixel form executes fewer products)
+            "roofline": {"kernel": dom["kernel"], "frac": round(dom["flops_executed"] / (dom["total_ms"] * 1e-3) / 1e12 / peak, 4),
+                         "frac_algorithmic": round(dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12 / peak, 4), "peak": peak,
+                         "forward_executed_frac": round(mf_ex / (mf_ms * 1e-3) / 1e12 / peak, 4),
+                         "forward_algorithmic_frac": round(sum(r["flops"] for r in mfma) / (mf_ms * 1e-3) / 1e12 / peak, 4),
+                         "attention_ms": round(att_ms, 4)},
             "parity": parity}
 
 
 def main():
     faulthandler.enable()
+    if "--cpu-all-cores-probe" in sys.argv[1:]:
+        return cpu_all_cores_probe()
     # The contract is ONE line on stdout.  RCCL prints a version banner through C stdio (it shows up after the JSON line
     # when the process exits), so everything written to file descriptor 1 during the run is sent to stderr and the JSON
     # line goes to the real stdout at the very end.
@@ -494,8 +547,24 @@ def main():
     if rank == 0:
         g = state.get("graph_out")
         timed_image0 = torch.cat([g["composed"][0:1], g["mask"][0:1]], 1) if g else outs[state["last"]][0:1].clone()
+    per_rank_ms, fwd_only_ms = None, None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        # diagnostics for the first real multi-GPU run (VERDICT r4 'Next round' 8), outside the timed region: every rank's own
+        # ms/step, and the forward alone (no gather) over a few steps -- ms_per_step minus that is the EXPOSED part of the gather
+        nfo = max(1, min(args.steps, 10))
+        torch.cuda.synchronize(dev)
+        tf = time.perf_counter()
+        for _ in range(nfo):
+            forward(outs[0])
+        torch.cuda.synchronize(dev)
+        fwd_only = 1e3 * (time.perf_counter() - tf) / nfo
+        cdev = dev if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([1e3 * elapsed / args.steps, fwd_only], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(float(a[0]), 4) for a in allr]
+        fwd_only_ms = [round(float(a[1]), 4) for a in allr]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if args.check_gather:
@@ -539,7 +608,11 @@ def main():
         mf_ex = sum(r["flops_executed"] for r in mfma) / nprof
         mf_al = sum(r["flops"] for r in mfma) / nprof
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(executed, 3), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(executed / peak, 4), "traffic": None, "traffic_source": None,
+                    "unit": "TFLOP/s", "frac": round(executed / peak, 4),
+                    # SURVEY.md 8(d)'s definition: reference-defined FLOPs per launch / launch duration / peak -- above 1 when the
+                    # kernel is a Winograd form (24 of 72 products executed); `frac` is the share of the MFMA pipe really used
+                    "frac_algorithmic": round(algorithmic / peak, 4),
+                    "traffic": None, "traffic_source": None,
                     "achieved_is": "executed multiply-add FLOPs per launch / average launch duration (HIP events)",
                     "algorithmic_tflops": round(algorithmic, 3),
                     "executed_over_algorithmic": round(dom["flops_executed"] / dom["flops"], 4),
@@ -552,6 +625,7 @@ def main():
                     "forward_executed_tflops": round(mf_ex / (mf_ms * 1e-3) / 1e12, 3),
                     "forward_executed_frac": round(mf_ex / (mf_ms * 1e-3) / 1e12 / peak, 4),
                     "forward_algorithmic_tflops": round(mf_al / (mf_ms * 1e-3) / 1e12, 3),
+                    "forward_algorithmic_frac": round(mf_al / (mf_ms * 1e-3) / 1e12 / peak, 4),
                     # time-weighted share of the 256 CUs that the MFMA kernels' grids can occupy (one workgroup per CU
                     # counted as occupied; the batch-1 figure the low-latency mode exists to raise)
                     "cu_occupancy_by_grid": round(sum(r["total_ms"] * min(1.0, r.get("workgroups", 0) / 256.0) for r in mfma) /
@@ -567,6 +641,7 @@ def main():
             if t_us:     # the same figure from the rocprofv3 --kernel-trace child run (no event pairs around the launches)
                 roofline["rocprofv3_avg_launch_us"] = t_us["avg_us"]
                 roofline["rocprofv3_frac"] = round(dom["flops_executed"] / dom["launches"] / (t_us["avg_us"] * 1e-6) / 1e12 / peak, 4)
+                roofline["rocprofv3_frac_algorithmic"] = round(dom["flops"] / dom["launches"] / (t_us["avg_us"] * 1e-6) / 1e12 / peak, 4)
                 roofline["rocprofv3_all"] = dict(TRACE_US)
 
     # ---- parity of this very run against the oracle on image 0 (CPU, rank 0)
@@ -627,10 +702,18 @@ def main():
                        "global_batch": world * B, "size": S, "per_gpu_batch": B,
                        "execution": ("low-latency" if ll_on else "default") + ("+graph" if args.graph else ""),
                        "host_placement_rank0": placement,
-                       "collective": ("one all_gather of the packed (B,4,H,W) outputs per step" +
-                                      (" on a side stream, under the next step's forward" if overlap else "") +
-                                      ("; NCCL_MAX_NCHANNELS=%s" % os.environ.get("NCCL_MAX_NCHANNELS") if args.backend == "nccl" else "")
-                                      ) if use_dist else None},
+                       "collective": ({"what": "one all_gather of the packed (B,4,H,W) outputs per step" +
+                                               (" on a side stream, under the next step's forward" if overlap else ""),
+                                       "backend": args.backend,
+                                       "nccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None),
+                                       "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                                       "bytes_per_rank_per_step": B * 4 * S * S * 4,
+                                       "per_rank_ms_per_step": per_rank_ms,
+                                       "per_rank_forward_only_ms": fwd_only_ms,
+                                       # what the side-stream overlap did not hide (slowest rank): ms/step with the gather
+                                       # minus the forward alone, un-timed leg of min(steps, 10) forwards
+                                       "exposed_gather_ms": round(max(per_rank_ms) - max(fwd_only_ms), 4)}
+                                      if use_dist else None)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "secondary": secondary, "kernels": kernels,
             "layers": ({r["layer"]: {"ms": round(r["total_ms"] / nprof, 4), "n": r["launches"] // nprof,
                                      "tflops_executed": round(r["flops_executed"] / (r["total_ms"] * 1e-3) / 1e12, 1)}

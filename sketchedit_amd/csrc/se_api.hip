@@ -577,7 +577,8 @@ int pack_rtilew(se_ctx* c, Layer& L) {
   HIPCHK(c, hipMalloc(&L.d_wx, img.size() * 4));
   HIPCHK(c, hipMemcpy(L.d_wx, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   // two-dimensional form: U = G g G^T per position; a row holds its 24 k as channels 0-15 in slots 0-3 and channels
-  // 16 + 2q, 17 + 2q in the first two elements of slot 4 + q (k-half 1 issues two k-steps)
+  // 16 + 2q, 17 + 2q in slot 4 + q, elements 0, 1 for even q and 2, 3 for odd q (k-half 1 issues two k-steps; the halves keep
+  // the 8-byte fragment reads of lane groups q, q ^ 1 off each other's banks, se_rtilew.hip)
   std::vector<float> img2((size_t)16 * 24 * 32, 0.f);
   for (int prow = 0; prow < 24; ++prow) {
     const int oc = prow < 8 ? prow : prow < 16 ? G + (prow - 8) : prow < 20 ? 8 + (prow - 16) : G + 8 + (prow - 20);
@@ -589,7 +590,7 @@ int pack_rtilew(se_ctx* c, Layer& L) {
       for (int pos = 0; pos < 16; ++pos) {
         const int xi = pos >> 2, nu = pos & 3;
         const float u = t[xi][0] * Gm[nu][0] + t[xi][1] * Gm[nu][1] + t[xi][2] * Gm[nu][2];
-        const int s_ = ic < 16 ? ic / 4 : 4 + (ic - 16) / 2, e = ic < 16 ? ic % 4 : (ic - 16) % 2;
+        const int s_ = ic < 16 ? ic / 4 : 4 + (ic - 16) / 2, e = ic < 16 ? ic % 4 : (ic - 16) % 2 + 2 * (((ic - 16) / 2) & 1);
         const int ps = s_ ^ ((prow >> 1) & 7);
         img2[((size_t)pos * 24 + prow) * 32 + ps * 4 + e] = u;
       }
@@ -1705,6 +1706,9 @@ int se_create(int device_id, se_ctx** out) {
   }
   for (int i = 0; i < NG; ++i) c->G[G_LAYERS[i].name].def = G_LAYERS[i];
   for (int i = 0; i < NM; ++i) c->M[M_LAYERS[i].name].def = M_LAYERS[i];
+  // (the 4-channel form of wconv1 is planned by the dry runs of se_workspace_bytes before any weight exists: a zero stride in
+  // its definition was a division by zero for a ctx that had only netM's weights -- found by tools/f43_flips.py, round 5)
+  c->wconv1_j4.def = c->G.at("wconv1").def;
   *out = c;
   return 0;
 }

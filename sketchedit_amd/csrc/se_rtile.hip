@@ -351,16 +351,35 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
 // ~4.6k cycles of MFMAs, ~2.6k of other VALU work (transform, the A^T folds: 120 instructions per block, epilogue) that the
 // MFMAs exclude, and ~3.7k cycles' worth of LDS traffic (fragment reads, 32 % bank conflicts on the dword gathers) in 10.6k.
 // ---------------------------------------------------------------------------------------------------------------------
+// Layout of T (round 5; VERDICT r4 item 2: 24-31 % of this kernel's LDS cycles were bank-conflict cycles).  The B operand of a
+// k-step is four ds_read_b32 per lane; the 32 lanes of a lane group (two tile rows rl x eight x-tiles xt x two k lane groups)
+// read dword (2w + rl + ky) * TROW + nu * TNU + xt * XS + c, and with the dense strides (XS = CD, TROW = 48 CD dwords: a
+// multiple of 16) the two tile rows -- and for CD = 4 every pair of lanes -- fell on the same banks: 60 / 80 / 104 LDS cycles
+// per wave and position loop where 32 / 40 / 56 are conflict-free.  Padded strides found by exhaustive search over (x-tile
+// stride, pad per nu plane, pad per row) with the ds_read_b32 bank model of MI355X_MICROARCH.md (32 banks per 32-lane group):
+//   CD = 3: x-tile stride 4 dwords, row pad 2 -> 40 cycles;   CD = 4: row pad 2 -> 40 (conflict-free);
+//   CD = 5: x-tile stride 6, nu-plane pad 2, row pad 4 -> 64.
+// (ds_write_b32 of the transform pass: a 2-way conflict costs a store nothing, same guide.)
+template <int CD> struct D5WLayout {
+  static constexpr int XS = CD == 3 ? 4 : (CD == 5 ? 6 : CD);        // dwords between x-tiles
+  static constexpr int NUPAD = CD == 5 ? 2 : 0;                      // dwords behind the eight x-tiles of one (row, nu)
+  static constexpr int ROWPAD = CD == 5 ? 4 : 2;                     // dwords behind the six nu planes of one row
+  static constexpr int TNU = (8 * XS + NUPAD) * 4;                   // bytes of one (row, nu) plane
+  static constexpr int TROW = 6 * TNU + ROWPAD * 4;                  // bytes of one source row of T
+  static constexpr int TBYTES = (12 * TROW + 255) & ~255;
+};
 template <int CD>
 __global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams p) {
   constexpr int NT = 3, TR = 8, KH = 5;
   constexpr int RH = TR + KH - 1, RW = 20;                 // raw tile: 12 x 20 source pixels (columns tx0 - 2 .. tx0 + 17)
   constexpr int NDW = RH * RW * CD;
   constexpr int K = KH * CD, KS = (K + 3) / 4;             // k per position, MFMA k-steps per position
-  constexpr int TNU = 8 * CD * 4;                          // bytes of the eight x-tiles of one (row, nu)
-  constexpr int TROW = 6 * TNU;                            // bytes of one source row of T
+  constexpr int XS = D5WLayout<CD>::XS;
+  constexpr int TNU = D5WLayout<CD>::TNU;                  // bytes of the eight x-tiles of one (row, nu)
+  constexpr int TROW = D5WLayout<CD>::TROW;                // bytes of one source row of T
   constexpr int RAWB = (NDW * 4 + 1023) & ~1023;
-  constexpr int TBYTES = (RH * TROW + 255) & ~255;
+  constexpr int TBYTES = D5WLayout<CD>::TBYTES;
+  static_assert(RH == 12, "D5WLayout::TBYTES assumes 12 source rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Raw = smem;
   char* T = smem + RAWB;
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams
     const float* src = (const float*)(Raw + ((row * RW + 2 * xt) * CD + c) * 4);
     const float d0 = src[0], d1 = src[CD], d2 = src[2 * CD], d3 = src[3 * CD], d4 = src[4 * CD], d5 = src[5 * CD];
     const float pp = fmaf(-4.f, d2, d4), qq = fmaf(-4.f, d1, d3), rr = d4 - d2, tt = d3 - d1;
-    float* dst = (float*)(T + row * TROW + xt * CD * 4 + c * 4);
+    float* dst = (float*)(T + row * TROW + xt * XS * 4 + c * 4);
     dst[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
     dst[TNU / 4] = pp + qq;
     dst[2 * TNU / 4] = pp - qq;
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams
   frag_offsets(lane, off0, off1);
   const int jx = lane & 15, g4 = lane >> 4;
   const int rl = jx >> 3, xt = jx & 7;
-  const int xbase = (2 * w + rl) * TROW + xt * CD * 4;
+  const int xbase = (2 * w + rl) * TROW + xt * XS * 4;
   // this lane group's four (k-half 0) + four (k-half 1) element offsets
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 to0 = *(const i32x4*)(Tab + g4 * 4), to1 = *(const i32x4*)(Tab + 16 + g4 * 4);
@@ -482,7 +501,8 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5w_kernel(const RTileParams
 template <int CD>
 static hipError_t launch_rtile_dense5w(const RTileParams& p, hipStream_t st) {
   constexpr int NDW = 12 * 20 * CD;
-  constexpr int LDS = ((NDW * 4 + 1023) & ~1023) + ((12 * 6 * 8 * CD * 4 + 255) & ~255) + 128 + 6 * 48 * 128;
+  constexpr int LDS = ((NDW * 4 + 1023) & ~1023) + D5WLayout<CD>::TBYTES + 128 + 6 * 48 * 128;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
   hipError_t e = ensure_max_lds((const void*)rtile_dense5w_kernel<CD>, 80 * 1024);
   if (e != hipSuccess) return e;
   const int tiles = p.B * p.ty * p.tx;

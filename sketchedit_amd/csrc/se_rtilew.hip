@@ -316,7 +316,10 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
       const f32x4 c0 = d[i][2] * negone + d[i][0], c1 = d[i][1] + d[i][2], c2 = d[i][1] * negone + d[i][2], c3 = d[i][3] * negone + d[i][1];
       d[i][0] = c0; d[i][1] = c1; d[i][2] = c2; d[i][3] = c3;
     }
-    char* at = T + tt * ENT + tgr * 16;
+    // granules 4, 5 (channels 16-23: the 8-byte k-half-1 pieces) are stored swapped in the tiles with bit 3 set, so that the
+    // ds_read_b64 of tiles j and j + 8 -- 8 * 96 bytes = 3 bank rows apart -- fall on different halves of the 32-byte region
+    // (round 5: these reads were 2-way bank conflicts, 41 % of the kernel's LDS cycles; conflict-free now, same bytes read)
+    char* at = T + tt * ENT + (tgr >= 4 ? tgr ^ ((tt >> 3) & 1) : tgr) * 16;
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
       *(f32x4*)(at + (0 * 4 + nu) * TPOS) = d[2][nu] * negone + d[0][nu];
@@ -328,10 +331,13 @@ __global__ __launch_bounds__(512, 2) void rtilew2_kernel(const RTileParams p) {
 
   const int jx = lane & 15, g4 = lane >> 4;
   // B fragments: this lane's tile of the wave's column tile; k-half 0 = granule g4, k-half 1 = the 8-byte piece g4 of channels 16-23
-  const int xoff0 = (ct * 16 + jx) * ENT + g4 * 16, xoff1 = (ct * 16 + jx) * ENT + 64 + g4 * 8;
+  // (piece g4 of a tile with bit 3 set lives at piece g4 ^ 2: the transform stores granules 4 and 5 swapped there)
+  const int xoff0 = (ct * 16 + jx) * ENT + g4 * 16, xoff1 = (ct * 16 + jx) * ENT + 64 + (g4 ^ ((jx >> 3) << 1)) * 8;
   // A fragments: physical weight row of this lane's packed row, with the usual slot swizzle
   const int prow = rt == 0 ? jx : 16 + ((jx >> 3) << 2) + (jx & 3);
-  const int aoff0 = prow * 128 + ((g4 ^ ((prow >> 1) & 7)) << 4), aoff1 = prow * 128 + (((4 + g4) ^ ((prow >> 1) & 7)) << 4);
+  // (k-half 1: channels 16 + 2 g4, 17 + 2 g4 sit in the lower / upper 8 bytes of slot 4 + g4 for even / odd g4 (pack_rtilew):
+  // lane groups g4 and g4 ^ 1 of rows 2k, 2k + 2 share a slot after the swizzle -- in different halves, no bank conflict)
+  const int aoff0 = prow * 128 + ((g4 ^ ((prow >> 1) & 7)) << 4), aoff1 = prow * 128 + (((4 + g4) ^ ((prow >> 1) & 7)) << 4) + (g4 & 1) * 8;
   const f32x4 bias4 = *(const f32x4*)(p.bias + rt * 16 + g4 * 4);
   float neg1 = -1.f;
   asm volatile("" : "+v"(neg1));

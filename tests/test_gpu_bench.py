@@ -34,6 +34,7 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and 0.0 < roof["frac"] <= 1.0 and roof["peak"] == 157.3
+    assert roof["frac_algorithmic"] > 0.0                     # SURVEY 8(d)'s definition beside the executed share (may exceed 1)
     assert d["parity"]["max_abs_composed"] < 1e-3 or d["parity"].get("max_abs_composed_same_hard_mask", 1.0) < 1e-3
 
 
@@ -48,7 +49,12 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["per_gpu_batch"] == 2
-    assert d["config"]["collective"] and "all_gather" in d["config"]["collective"]
+    col = d["config"]["collective"]
+    assert col and "all_gather" in col["what"] and col["backend"] == "gloo"
+    # diagnostics of the first real multi-GPU run: every rank's own ms/step, the forward alone, the exposed gather time
+    assert len(col["per_rank_ms_per_step"]) == 2 and len(col["per_rank_forward_only_ms"]) == 2
+    assert abs(max(col["per_rank_ms_per_step"]) - d["ms_per_step"]) < 0.05 * d["ms_per_step"] + 0.5
+    assert col["bytes_per_rank_per_step"] == d["config"]["per_gpu_batch"] * 4 * d["config"]["size"] ** 2 * 4
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # whole-job images per second
 
 

@@ -1,0 +1,112 @@
+// Microbenchmark (VERDICT r4 "Next round" 1a): v_mfma_f32_32x32x16_bf16 against v_mfma_f32_16x16x32_bf16 in the register
+// pattern of rconv16b_kernel (se_rconv16.hip) -- a wave tile of 96 packed rows x 64 pixels, every A (weight) and B (pixel)
+// fragment read from LDS with ds_read_b128, a 3-deep fragment window:
+//   16x16x32: per 32-k step 6 A + 4 B fragment reads, 24 MFMAs of 16 passes     (the kernel's loop today)
+//   32x32x16: per 16-k step 3 A + 2 B fragment reads,  6 MFMAs of 32 passes     (same bytes per multiply-add)
+// with 1 or 2 waves per SIMD (256 / 512 threads per block, 2 blocks per CU for 256).  Prints TFLOP/s per variant; the port is
+// worth it if the 32x32x16 row is >= 8 % faster in the LDS-fed form.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma32_rate tools/ubench/mfma32_rate.hip && ./mfma32_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 16x16x32: NT row tiles x PT pixel tiles of 16
+template <bool LDS>
+__global__ __launch_bounds__(256, 2) void k16(const f32x4* in, f32x4* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NT = 6, PT = 4;
+  f32x4 acc[NT][PT];
+  for (int i = 0; i < NT; ++i) for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) ((f32x4*)lds)[i] = in[i & 1023];
+  __syncthreads();
+  const char* base = lds + (threadIdx.x & 63) * 16;
+  bf16x8 a[NT], b[PT];
+  for (int i = 0; i < NT; ++i) a[i] = *(const bf16x8*)(base + i * 1024);
+  for (int j = 0; j < PT; ++j) b[j] = *(const bf16x8*)(base + (8 + j) * 1024);
+  for (int it = 0; it < iters; ++it) {
+    const char* s = base + (it & 3) * 12288;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      bf16x8 av = a[i];
+      if (LDS) av = *(const bf16x8*)(s + i * 1024);
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        bf16x8 bv = b[j];
+        if (LDS && i == j + 1) b[j] = *(const bf16x8*)(s + (6 + j) * 1024);      // next step's pixel fragments, one per MFMA group
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  f32x4 s4 = {0, 0, 0, 0};
+  for (int i = 0; i < NT; ++i) for (int j = 0; j < PT; ++j) s4 += acc[i][j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s4;
+}
+
+// 32x32x16: 3 row tiles x 2 pixel tiles of 32; two 16-k steps per iteration (= one 32-k step of the kernel above)
+template <bool LDS>
+__global__ __launch_bounds__(256, 2) void k32(const f32x4* in, f32x4* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NT = 3, PT = 2;
+  f32x16 acc[NT][PT];
+  for (int i = 0; i < NT; ++i) for (int j = 0; j < PT; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) ((f32x4*)lds)[i] = in[i & 1023];
+  __syncthreads();
+  const char* base = lds + (threadIdx.x & 63) * 16;
+  bf16x8 a[2][NT], b[2][PT];
+  for (int h = 0; h < 2; ++h) {
+    for (int i = 0; i < NT; ++i) a[h][i] = *(const bf16x8*)(base + (h * 5 + i) * 1024);
+    for (int j = 0; j < PT; ++j) b[h][j] = *(const bf16x8*)(base + (h * 5 + 3 + j) * 1024);
+  }
+  for (int it = 0; it < iters; ++it) {
+    const char* s = base + (it & 3) * 12288;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        bf16x8 av = a[h][i];
+        if (LDS) av = *(const bf16x8*)(s + (h * 5 + i) * 1024);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+          bf16x8 bv = b[h][j];
+          if (LDS && i == j) b[h][j] = *(const bf16x8*)(s + (h * 5 + 3 + j) * 1024);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+        }
+      }
+  }
+  f32x4 s4 = {0, 0, 0, 0};
+  for (int i = 0; i < NT; ++i) for (int j = 0; j < PT; ++j) for (int e = 0; e < 16; ++e) s4[e & 3] += acc[i][j][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s4;
+}
+
+template <typename K>
+void run(const char* name, K kern, int blocks_per_cu, f32x4* in, f32x4* out) {
+  // 96 KB of dynamic LDS: one block (4 waves, one per SIMD) per CU; 64 KB: two blocks (two waves per SIMD), as rconv16b runs
+  const int lds = blocks_per_cu == 1 ? 96 * 1024 : 64 * 1024;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int iters = 4000, blocks = 256 * blocks_per_cu * 2;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0.f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, in, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double fl = 2.0 * 96 * 64 * 32 * (double)iters * blocks * 4;      // 96 rows x 64 pixels x 32 k per wave and iteration
+  printf("%-44s %d block(s)/CU: %.3f ms  %.0f TFLOP/s\n", name, blocks_per_cu, ms, fl / ms / 1e9);
+}
+
+int main() {
+  f32x4 *in, *out;
+  hipMalloc(&in, 1024 * 16); hipMalloc(&out, 1 << 24);
+  hipMemset(in, 0x3c, 1024 * 16);
+  for (int bpc = 1; bpc <= 2; ++bpc) {
+    run("16x16x32 from registers", k16<false>, bpc, in, out);
+    run("32x32x16 from registers", k32<false>, bpc, in, out);
+    run("16x16x32 A and B fragments from LDS", k16<true>, bpc, in, out);
+    run("32x32x16 A and B fragments from LDS", k32<true>, bpc, in, out);
+  }
+  return 0;
+}
