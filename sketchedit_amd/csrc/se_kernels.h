@@ -49,7 +49,7 @@ hipError_t ensure_max_lds(const void* func, int bytes);
   X(TEST_OFFSET_LIMIT, 0) /* test aid, se_debug_set_option only: byte range of the 32-bit-offset kernels (0: 2^31) */ \
   X(RCONV16, 1) X(RCONV16_DUAL, 1) X(RCONV16_TILE, 8) X(RCONV96, 1) X(VECBIAS, 1)                              \
   X(WINOGRAD, 1) X(WINOGRAD48, 1) X(WINOGRAD_UP, 1) X(WINOGRAD_UP48, 1)                                         \
-  X(WINOGRAD_F43, 1)     /* hybrid F(2,3)xF(4,3): 0 off, 1 everywhere, 2 netG only, 3 everywhere but netM's mask decoder */ \
+  X(WINOGRAD_F43, 1)     /* hybrid F(2,3)xF(4,3): 0 off, 1 everywhere, 2 netG only */ \
   X(WINO48_TILES, 64) X(WINOUP_TILES, 64)                                                                       \
   X(GCONV_FAST, 1) X(GCONV_VARIANT_N192, 0) X(GCONV_VARIANT_N96, 0) X(GCONV_VARIANT_N48, 0) X(GCONV_VARIANT_N24, 0) \
   X(LL_STAGES, 2)                                                                                               \

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
     const int rt = j * 4 + w;
     glds16_s((const char*)p.wpk + (size_t)s * WSB + rt * 1024, (unsigned)lane * 16u, lds_w + (s % NS) * WSB + rt * 1024);
   };
-  // ---- prologue: weight step 0, the raw tile, weight step 1 (in this order: the loop's counted waits rely on it)
+  // ---- prologue: weight step 0, the raw tile, weight steps 1 and 2 (in this order: the loop's counted waits rely on it)
   dma_w(0, 0); dma_w(0, 1); dma_w(0, 2);
   // The raw tile, one ROW (18 pixels x 12 granules = 216 slots = 4 instructions of 54 lanes) at a time: wave w issues
   // quarter w of every row, so which column and granule a lane fetches is a per-lane constant and the row is wave-uniform
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
     if (w == 0 && lane < (RAWB - RSY * RSX * 192) / 16) bufdma16(0x80000000u, rsrc, lds_raw + RSY * RSX * 192);
   }
   dma_w(1, 0); dma_w(1, 1); dma_w(1, 2);
+  dma_w(2, 0); dma_w(2, 1); dma_w(2, 2);            // three steps ahead: every ring slot is in flight from the start
 
   int bk[3];
 #pragma unroll
@@ -292,41 +293,62 @@ __global__ __launch_bounds__(256, 2) void rconv16b_kernel(const RConvParams p) {
   auto afrag = [&](int s, int i) -> bf16x8 {           // wave row tile i = 0..5 of step s
     return *(const bf16x8*)(Wb + (s % NS) * WSB + aoff + (i < 3 ? i : i + 3) * 1024);
   };
-  // weight step 0 and the raw tile have landed when at most the 3 DMAs of step 1 are outstanding (loads retire in order)
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  // ---- main loop, barrier in the MIDDLE of a step (round 5).  The round-3 loop ended every step with vmcnt + barrier and
+  // began the next one with its first three A-fragment reads: every step opened with an LDS round trip that nothing of the
+  // wave's own could cover (its MFMAs were all behind those reads) -- with two waves per SIMD the pipe measured 51.6 % busy.
+  // Here the barrier of step s sits between its MFMA groups 2 and 3.  It publishes the DMA'd weights of step s + 1 and retires
+  // the LDS reads of step s's slot, so on its far side the wave (a) still holds three MFMA groups whose fragments were read
+  // BEFORE the barrier (bank B: row tiles 3-5 of step s, read at group 0), (b) reads row tiles 0-2 of step s + 1 (bank A) under
+  // them, and (c) refills the slot it has just left with step s + 3.  No MFMA group waits for a read issued after the last
+  // barrier, and a DMA has 2.5 steps of lead instead of 1.75.  Twelve more VGPRs (the second fragment bank; 186 in all).
+  // Measured (512 x 512 B=16, same box, two alternations): gconv_n192 2.838 -> 2.815 ms per step (-0.8 %) -- the step-opening
+  // round trip was a small part of the idle pipe time.  What the pipe can do at all in this register pattern is less than
+  // the nominal 2.5 PFLOP/s: tools/ubench/mfma32_rate.hip sustains 1671 TFLOP/s with both fragments LDS-fed on RANDOM bf16
+  // operands (2126 on constant ones: the part clocks to its power budget), and the same loop on v_mfma_f32_32x32x16_bf16 only
+  // 1532 -- which is why this kernel was not ported to the larger instruction (VERDICT r4 'Next round' 1a; profiles/r05_mfma32_rate.txt).
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // weight step 0 and the raw tile have landed (steps 1, 2 may be in flight)
   __syncthreads();
-  bf16x8 xb[PT], xn[PT];
+  bf16x8 xb[PT], xn[PT], wA[3], wB[3];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) xb[pt] = bfrag(0, pt);
 #pragma unroll
+  for (int u = 0; u < 3; ++u) wA[u] = afrag(0, u);
+#pragma unroll
   for (int s = 0; s < NSTEP; ++s) {       // fully unrolled: taps, ring slots and register rotation are compile-time
-    constexpr int DEPTH = 3;
-    bf16x8 wq[DEPTH];
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) wq[u] = afrag(s, u);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < 3; ++u) {         // groups 0-2: bank A (read in the second half of step s - 1)
+      if (u == 0) {
 #pragma unroll
-    for (int u = 0; u < NTW; ++u) {
-      const bf16x8 wa = wq[u % DEPTH];
-      if (u + DEPTH < NTW) wq[u % DEPTH] = afrag(s, u + DEPTH);
-      // the next step's pixel fragments (the raw tile never changes), one per MFMA group
-      if (u >= 1 && u < 1 + PT && s + 1 < NSTEP) xn[u - 1] = bfrag(s + 1, u - 1);
-      // pin the order (hipcc would sink every read to just in front of its MFMAs and wait lgkmcnt(0) there)
+        for (int i = 0; i < 3; ++i) wB[i] = afrag(s, 3 + i);          // bank B of THIS step: needed three groups from now
+      }
+      if (u == 1 && s + 1 < NSTEP) { xn[0] = bfrag(s + 1, 0); xn[1] = bfrag(s + 1, 1); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
-        acc[u][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[pt], acc[u][pt], 0, 0, 0);
-      // weight step s + 2 goes to the slot step s - 1 has left (everyone passed the barrier that ended it)
-      if (u < 3 && s + 2 < NSTEP) dma_w(s + 2, u);
+        acc[u][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[u], xb[pt], acc[u][pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s + 1 < NSTEP) {
+      // step s + 1 has landed when at most the 3 DMAs of step s + 2 are outstanding; every LDS read of slot s is retired
+      if (s + 2 < NSTEP) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 3; u < NTW; ++u) {       // groups 3-5: bank B; bank A of step s + 1 and the refill of this step's slot under them
+      if (s + 1 < NSTEP) wA[u - 3] = afrag(s + 1, u - 3);
+      if (u < 5 && s + 1 < NSTEP) xn[u - 1] = bfrag(s + 1, u - 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        acc[u][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wB[u - 3], xb[pt], acc[u][pt], 0, 0, 0);
+      if (s + 3 < NSTEP) dma_w(s + 3, u - 3);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) xb[pt] = xn[pt];
-    // step s + 1 was issued one step ago: at most the 3 DMAs of step s + 2 may still be in flight
-    if (s + 2 < NSTEP) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  __syncthreads();                        // the epilogue stages its tile in the raw tile's room: every wave is done reading it
 
   // ---- epilogue: bias, gate, transposed through LDS (the raw tile's room), 16-byte stores (see the kernel above)
   constexpr int OPX = 208;

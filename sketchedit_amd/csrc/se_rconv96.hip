@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256, 2) void rconv96_kernel(const RConv96Params p) 
 
   auto bfrag = [&](int s, int pt) -> bf16x8 { return *(const bf16x8*)(Raw + STRIDE * (4 * pg + pt) * ROWB + boff[s]); };
   auto afrag = [&](int s, int i) -> bf16x8 { return *(const bf16x8*)(Wb + (s % NS) * WSB + aoff + i * 1024); };
+  // (The mid-step barrier pipeline of rconv16b_kernel -- se_rconv16.hip, round 5 -- was ported here too and measured on the
+  // same box: gconv_n96 1.221 against 1.221 ms per 512 x 512 B=16 step.  Nothing to gain: not kept.)
   if (NSTEP > 1) wait_newest_step();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

@@ -358,12 +358,17 @@ __global__ __launch_bounds__(256, 2) void rtile_dense5_kernel(const RTileParams 
 // per wave and position loop where 32 / 40 / 56 are conflict-free.  Padded strides found by exhaustive search over (x-tile
 // stride, pad per nu plane, pad per row) with the ds_read_b32 bank model of MI355X_MICROARCH.md (32 banks per 32-lane group):
 //   CD = 3: x-tile stride 4 dwords, row pad 2 -> 40 cycles;   CD = 4: row pad 2 -> 40 (conflict-free);
-//   CD = 5: x-tile stride 6, nu-plane pad 2, row pad 4 -> 64.
-// (ds_write_b32 of the transform pass: a 2-way conflict costs a store nothing, same guide.)
+//   CD = 5: x-tile stride 6, nu-plane pad 2, row pad 4 -> 64 -- NOT used: its 3 KB of padding take the workgroup from 53.6 to
+//   56.7 KB, i.e. from THREE to two resident workgroups per CU, and the launch from 203 to 241 us (measured, same box); no
+//   layout within the 54.6 KB that three workgroups allow removes a conflict (x-tile stride 5 only), so CD = 5 stays dense.
+// Measured (256 x 256 B=32, same box, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE): CD = 4 24.0 -> 6.8 %, CD = 3 30.9 -> 20.2 % of
+// the LDS cycles; launch times unchanged (154.5 / 147 us): as DESIGN.md 7b had costed, the conflicts are not what binds these
+// kernels (MFMA + excluded VALU + LDS issue together do).  (ds_write_b32 of the transform pass: a 2-way conflict costs a store
+// nothing, same guide.)
 template <int CD> struct D5WLayout {
-  static constexpr int XS = CD == 3 ? 4 : (CD == 5 ? 6 : CD);        // dwords between x-tiles
-  static constexpr int NUPAD = CD == 5 ? 2 : 0;                      // dwords behind the eight x-tiles of one (row, nu)
-  static constexpr int ROWPAD = CD == 5 ? 4 : 2;                     // dwords behind the six nu planes of one row
+  static constexpr int XS = CD == 3 ? 4 : CD;                        // dwords between x-tiles
+  static constexpr int NUPAD = 0;                                    // dwords behind the eight x-tiles of one (row, nu)
+  static constexpr int ROWPAD = CD == 5 ? 0 : 2;                     // dwords behind the six nu planes of one row
   static constexpr int TNU = (8 * XS + NUPAD) * 4;                   // bytes of one (row, nu) plane
   static constexpr int TROW = 6 * TNU + ROWPAD * 4;                  // bytes of one source row of T
   static constexpr int TBYTES = (12 * TROW + 255) & ~255;

@@ -458,3 +458,20 @@ def test_symmetric_score_tile_enumeration():
                 assert (bx, by) not in seen
                 seen.add((bx, by))
         assert seen == {(bx, by) for by in range(ny) for bx in range(by // 4 + 1)}
+
+
+def test_bench_all_cores_cpu_sample_is_bounded():
+    """bench.py's cpu_baseline carries an all-cores sample beside the 32-thread figure (SURVEY.md 8d asked for all host cores;
+    oversubscribed oneDNN collapses on the 256-thread GPU hosts, so the leg is a child process stopped after a budget):
+    whatever it reports, it reports within the budget, with the thread count stated."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("se_bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t0 = time.perf_counter()
+    r = bench.cpu_all_cores_sample(os.cpu_count() or 1, budget_s=20.0)
+    assert time.perf_counter() - t0 < 40.0
+    assert r["threads"] == (os.cpu_count() or 1) and "note" in r
+    assert r["images_per_sec"] is None or r["images_per_sec"] > 0.0

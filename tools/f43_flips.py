@@ -5,7 +5,8 @@ netM's soft mask feeds `mask > 0.5` (editline2_model.py:346-347), so rounding er
 pixel of netG's INPUT.  The hybrid F(2,3) x F(4,3) kernel (se_wino24.hip) has non-dyadic constants and about twice the
 rounding error of F(2x2,3x3); this tool measures what that costs, per mode
     0  F(2x2,3x3) everywhere          1  hybrid everywhere
-    2  hybrid in netG only            3  hybrid everywhere except netM's mask decoder (conv_mask_11 / conv_mask_12)
+    2  hybrid in netG only            (3: hybrid everywhere except netM's mask decoder -- measured in round 5: as many flips
+                                       as mode 1, removed from the library)
 against the fp32 oracle: flips of the hard mask, max / mean |soft mask error|, and the mean error over the pixels whose
 oracle value lies in [0.4, 0.6] (the ones a larger error could flip), over the three procedural weight sets and N seeded
 inputs per set at 256x256 (+ N/4 at 512x512).   usage: python tools/f43_flips.py [N=16] > f43_flips.json
@@ -26,7 +27,7 @@ from sketchedit_amd import _lib, synth  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    res = {m: {"flips": 0, "pixels": 0, "max_abs": 0.0, "sum_abs": 0.0, "near": 0, "near_sum_abs": 0.0, "near_max_abs": 0.0} for m in (0, 1, 2, 3)}
+    res = {m: {"flips": 0, "pixels": 0, "max_abs": 0.0, "sum_abs": 0.0, "near": 0, "near_sum_abs": 0.0, "near_max_abs": 0.0} for m in (0, 1, 2)}
     per_set = {}
     for ws in sorted(synth.WEIGHT_SETS):
         WM = synth.make_weight_set("M", ws)
