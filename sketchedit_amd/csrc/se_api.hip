@@ -76,6 +76,7 @@ struct Layer {
   // bf16 image (BASELINE config 5): same row order and slot swizzle, 64 bf16 k-values per 128-byte row, 8-channel granules
   float* d_w16 = nullptr;
   int nch16 = 0, CGp16 = 0;
+  float* d_w16d = nullptr;    // bf16, 5x5 layers whose stored input has <= 4 real channels: pair-of-taps image (pack_layer16_d4, se_rtile.hip)
   float* d_w16s = nullptr;    // 96 -> 192 3x3 only: the 32-k step image of the 8 x 16 raw-tile kernel (se_rconv16.hip)
   float* d_w96 = nullptr;     // 96-row stride-1 layers: the 32-k step image of se_rconv96.hip
   float* d_u1 = nullptr;      // two-source 96+96 -> 192 layers: Winograd image of the FIRST source's 96 channels alone, and
@@ -424,6 +425,33 @@ int pack_layer16(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   HIPCHK(c, hipMalloc(&L.d_w16, img.size() * 2));
   HIPCHK(c, hipMemcpy(L.d_w16, img.data(), img.size() * 2, hipMemcpyHostToDevice));
   L.nch16 = nch; L.CGp16 = Cp / 8;
+  return 0;
+}
+
+// bf16 pair-of-taps image of a 5x5 first layer whose stored NHWC8 input carries at most four real channels (rtile_kernel<3, 8,
+// true, true>): granule gi = 3 ky + j (j = 0..2) holds the taps (ky, 2j) and (ky, 2j + 1) x stored channels 0-3, i.e. element
+// e = 4 (kx & 1) + c; kx = 5 does not exist (zero).  15 granules -> 2 chunks of 64 k; rows in the MIXED N=48 order, slot swizzle
+// as pack_layer16.  cin4[c] = checkpoint input channel of stored channel c, or -1.
+int pack_layer16_d4(se_ctx* c, Layer& L, const int (&cin4)[4]) {
+  const LayerDef& d = L.def;
+  const int G = d.cout / 2, NP = 48, nch = 2;
+  std::vector<unsigned short> img((size_t)nch * NP * 64, 0);
+  for (int n = 0; n < NP; ++n) {
+    const int oc = out_channel_of_row(GC_N48, n, G, d.cout);
+    if (oc < 0) continue;
+    for (int ky = 0; ky < 5; ++ky)
+      for (int kx = 0; kx < 5; ++kx)
+        for (int cc = 0; cc < 4; ++cc) {
+          const int ic = cin4[cc];
+          if (ic < 0) continue;
+          const int gi = 3 * ky + kx / 2, e = 4 * (kx & 1) + cc;
+          const int ch = gi / 8, s_ = gi % 8, ps = s_ ^ ((n >> 1) & 7);
+          img[((size_t)ch * NP + n) * 64 + ps * 8 + e] = bf16_bits(L.w[(((size_t)oc * d.cin + ic) * 5 + ky) * 5 + kx]);
+        }
+  }
+  if (L.d_w16d) (void)hipFree(L.d_w16d);
+  HIPCHK(c, hipMalloc(&L.d_w16d, img.size() * 2));
+  HIPCHK(c, hipMemcpy(L.d_w16d, img.data(), img.size() * 2, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -841,6 +869,12 @@ int pack_net_layer(se_ctx* c, Layer& L) {
       J.def = d; J.w = L.w; J.b = L.b; J.have_w = J.have_b = true;
       const int rc = pack_layer16(c, J, std::vector<int>{0, 1, 2, 4, -1, -1, -1, -1});
       if (rc) return rc;
+      if (pack_layer16_d4(c, J, {0, 1, 2, 4})) return 1;
+    }
+    // 5x5 first layers with at most four real input channels: the pair-of-taps image beside the 8-channel-granule one
+    if (d.k == 5 && d.stride == 1 && d.rate == 1 && d.cout == 48 && d.cin >= 3 && d.cin <= 4) {
+      const int m4[4] = {0, 1, 2, d.cin == 4 ? 3 : -1};
+      if (pack_layer16_d4(c, L, m4)) return 1;
     }
     const int rc = pack_layer16(c, L, identity_map8(d.cin));
     if (rc) return rc;
@@ -942,6 +976,28 @@ int try_rtile(se_ctx* c, const Layer& L, bool bf, const float* src0, int C0, con
                       2.0 * (double)nb * Hin * Win * 48.0 * (4.0 * ((25 * L.dense + 3) / 4)));       // ceil(K / 4) k-steps of 4
       HIPCHK(c, launch_rtile(p, c->st));
     }
+    *done = true;
+    return 0;
+  }
+  // bf16: pair-of-taps form of the 5x5 first layers whose stored NHWC8 input has at most four real channels (SE_RTILE_DENSE=0:
+  // the 8-channel-granule K)
+  if (opt(OPT_RTILE_DENSE) != 0 && bf && L.d_w16d && d.k == 5 && !d.up && L.cfg == GC_N48 && C0 == 8 &&
+      (long long)B * Hin * Win * 16 < (1ll << 31)) {
+    RTileParams p;
+    memset(&p, 0, sizeof p);
+    p.src = src0; p.wpk = L.d_w16d; p.bias = L.d_b; p.dst = dst;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.C = C0; p.CG = 1; p.T = 25; p.KW = 5;
+    p.pad = pad; p.OH = Ho; p.OW = Wo; p.G = (L.G + 7) & ~7;
+    p.nch = 2; p.NP = 48; p.RH = 32 + 4; p.RW = 21;                     // one column more than the halo: the sixth tap of a pair row
+    p.raw_bytes = (p.RH * p.RW * 8 + 1023) & ~1023;
+    udiv_magic_host((unsigned)p.RW, &p.div_rw_m, &p.div_rw_l);
+    udiv_magic_host(1u, &p.div_cg_m, &p.div_cg_l);
+    p.ty = (Hin + 31) / 32; p.tx = (Win + 15) / 16;
+    p.act = d.act; p.bf16 = 1; p.xcd = xcd_remap_enabled(); p.dense = 204;
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 25;
+    set_launch_cost(alg, 2.0 * ((double)B * Hin * Win * d.cin + (double)B * Ho * Wo * (d.cout / 2)), d.name,
+                    2.0 * (double)B * Hin * Win * 48.0 * 128.0);
+    HIPCHK(c, launch_rtile(p, c->st));
     *done = true;
     return 0;
   }
@@ -1726,6 +1782,7 @@ void se_destroy(se_ctx* c) {
       if (kv.second.d_ub) (void)hipFree(kv.second.d_ub);
       if (kv.second.d_w16) (void)hipFree(kv.second.d_w16);
       if (kv.second.d_w16s) (void)hipFree(kv.second.d_w16s);
+      if (kv.second.d_w16d) (void)hipFree(kv.second.d_w16d);
       if (kv.second.d_w96) (void)hipFree(kv.second.d_w96);
       if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
       if (kv.second.d_wdw) (void)hipFree(kv.second.d_wdw);
@@ -1741,6 +1798,7 @@ void se_destroy(se_ctx* c) {
   if (c->wconv1_j4.d_w) (void)hipFree(c->wconv1_j4.d_w);
   if (c->wconv1_j4.d_b) (void)hipFree(c->wconv1_j4.d_b);
   if (c->wconv1_j4.d_w16) (void)hipFree(c->wconv1_j4.d_w16);
+  if (c->wconv1_j4.d_w16d) (void)hipFree(c->wconv1_j4.d_w16d);
   if (c->wconv1_j4.d_wd) (void)hipFree(c->wconv1_j4.d_wd);
   if (c->wconv1_j4.d_wdw) (void)hipFree(c->wconv1_j4.d_wdw);
   if (c->zeros) (void)hipFree(c->zeros);
@@ -2132,6 +2190,10 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
       rc = pack_layer_dense(c, L, id);
     }
     if (!rc && bf) rc = pack_layer16(c, L, identity_map8(CinT));
+    if (!rc && bf && k == 5 && stride == 1 && rate == 1 && Cout == 48 && !Cin1 && !upsample && Cin >= 3 && Cin <= 4) {
+      const int m4[4] = {0, 1, 2, Cin == 4 ? 3 : -1};
+      rc = pack_layer16_d4(c, L, m4);
+    }
     if (!rc && bf && k == 3 && stride == 1 && !upsample && Cout == 192 && ((CinT == 96 && !Cin1) || (CinT == 192 && Cin1 == 96))) rc = pack_rconv16(c, L);
     if (!rc && bf && !Cin1 && rconv96_eligible(L.def)) rc = pack_rconv96(c, L);
     if (!rc) {
@@ -2158,6 +2220,7 @@ int se_gated_conv2d_ex(se_ctx* c, void* stream, const float* x, const float* x1,
   if (L.d_ub) (void)hipFree(L.d_ub);
   if (L.d_w16) (void)hipFree(L.d_w16);
   if (L.d_w16s) (void)hipFree(L.d_w16s);
+  if (L.d_w16d) (void)hipFree(L.d_w16d);
   if (L.d_w96) (void)hipFree(L.d_w96);
   if (L.d_wd) (void)hipFree(L.d_wd);
   if (L.d_wdw) (void)hipFree(L.d_wdw);

@@ -224,7 +224,9 @@ struct RTileParams {
   int ty, tx;          // 8 x 16 tiles per image
   int act, bf16, xcd;
   int dense;           // > 0: dense-K form of the 5x5 first layers (fp32): `dense` = real input channels (3 or 5) out of the C
-                       // stored per pixel; wpk is then the image of pack_layer_dense (k = tap * dense + channel, no channel padding)
+                       // stored per pixel; wpk is then the image of pack_layer_dense (k = tap * dense + channel, no channel padding);
+                       // + 100: its F(2,5)-along-x form; 204: the bf16 pair-of-taps form (rtile_kernel<3, 8, true, true>:
+                       // 8-byte pixels = the first four stored channels, wpk = image of pack_layer16_d4, RW = 21)
 };
 hipError_t launch_rtile(const RTileParams& p, hipStream_t st);
 // 24 -> 24 3x3 stride 1 with F(2,3) along x (se_rtilew.hip): src NHWC 24, wpk = image of pack_rtilew ([4 positions][3 chunks]

@@ -25,8 +25,16 @@
 
 namespace se {
 
-template <int NT, int PT, bool BF16>
+// D4 (bf16, round 5): dense-K form of the 5x5 first layers whose stored NHWC8 input carries at most FOUR real channels (conv1
+// of netM, the 4-channel wconv1, xconv1 / pmconv1).  With 8-channel granules K = 25 taps x 8 = 200 -> 4 chunks of 64, of
+// which 75-100 k are real.  Here the raw tile holds 8-byte pixels -- the first four channels, staged one dword per DMA lane --
+// so the 16 bytes at pixel x are the four channels of taps kx and kx + 1: a k-granule is a PAIR of horizontally adjacent taps,
+// K = 5 rows x 3 pairs x 8 = 120 -> 2 chunks (the sixth tap of a row has zero weights: pack_layer16_d4), half the MFMAs and
+// half the A-fragment reads.  A pixel is only 8-byte aligned, and a misaligned ds_read_b128 is replayed at 64 cycles
+// (cdna_hip_programming.md, Guideline 17): a B fragment is two 8-byte reads.  Rows, MIXED order, epilogue: unchanged.
+template <int NT, int PT, bool BF16, bool D4 = false>
 __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
+  static_assert(!D4 || BF16, "the pair-of-taps form exists in bf16 only (fp32: rtile_dense5_kernel)");
   constexpr int ES = BF16 ? 2 : 4;           // bytes per stored element
   constexpr int TR = 4 * PT;                 // a wave = PT rows of 16 output pixels, a workgroup = TR x 16 outputs
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,7 +74,18 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
     const int slots = p.RH * p.RW * cgp;
     const int rowslots = p.RW * cgp;
     const int G = rowslots <= 32 ? 64 / rowslots : 1, GL = G * rowslots, NI = (GL + 63) >> 6;
-    if (NI == 1 || NI == 2 || NI == 4) {
+    if constexpr (D4) {
+      // 8-byte pixels: dword q of the tile = (pixel q >> 1, half q & 1) <- bytes 4 (q & 1) .. + 3 of the 16-byte source pixel
+      const int ndw = p.RH * p.RW * 2;
+      for (int i = w; i * 64 < ndw; i += 4) {
+        const int q = i * 64 + lane, pix = q >> 1;
+        const int row = (int)udiv_magic((unsigned)pix, p.div_rw_m, p.div_rw_l), c = pix - row * p.RW;
+        const int sy = ty0 - pady + row, sx = tx0 - padx + c;
+        const bool ok = q < ndw && (unsigned)sy < (unsigned)p.Hin && (unsigned)sx < (unsigned)p.Win;
+        const unsigned off = (unsigned)((b * p.Hin + sy) * p.Win + sx) * (unsigned)pixb + (unsigned)(q & 1) * 4u;
+        bufdma4(ok ? off : 0x80000000u, rsrc, lds_raw + i * 256);      // outside the image: hardware zero fill
+      }
+    } else if (NI == 1 || NI == 2 || NI == 4) {
       const int sh = NI == 1 ? 0 : (NI == 2 ? 1 : 2);
       const int LPI = (GL + NI - 1) >> sh, kp = w & (NI - 1), g0 = w >> sh, gstep = 4 >> sh;
       const int sl = kp * LPI + lane;                                  // this lane's slot of a group
@@ -99,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
   int off0, off1;
   frag_offsets(lane, off0, off1);
   const int jx = lane & 15, g4 = lane >> 4;
-  const int rowb = p.RW * pixb;                                          // bytes per raw tile row
-  const int xbase = ((PT * w) * p.RW + jx) * pixb;                        // this lane's pixel of the wave's first row
+  const int rowb = p.RW * (D4 ? 8 : pixb);                                // bytes per raw tile row
+  const int xbase = ((PT * w) * p.RW + jx) * (D4 ? 8 : pixb);              // this lane's pixel of the wave's first row
 
   // accumulators start at the bias: the epilogue has no bias add (its ordinary VALU instructions cost MFMA slots)
   f32x4 acc[NT][PT];
@@ -133,9 +152,23 @@ __global__ __launch_bounds__(256, 2) void rtile_kernel(const RTileParams p) {
       wq[u] = *(const frag_t*)(Wres + ch * (p.NP * 128) + (u % NT) * 2048 + (u / NT ? off1 : off0));
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const int xo = xbase + tap_off(ch * 8 + half * 4 + g4);
+      if constexpr (D4) {
+        // granule gi = 3 ky + j: the taps (ky, 2j) and (ky, 2j + 1); gi = 15 is chunk padding (zero weights: any valid address)
+        const int gi = min(ch * 8 + half * 4 + g4, 14);
+        const int ky = (gi * 11) >> 5, j = gi - 3 * ky;                    // gi / 3 for gi <= 14
+        const int xo = xbase + ky * rowb + j * 16;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) xb[half][pt] = *(const frag_t*)(Raw + xo + pt * rowb);
+        for (int pt = 0; pt < PT; ++pt) {
+          const u32x2 lo = *(const u32x2*)(Raw + xo + pt * rowb), hi = *(const u32x2*)(Raw + xo + pt * rowb + 8);
+          xb[half][pt] = __builtin_bit_cast(frag_t, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+        }
+      } else {
+        const int xo = xbase + tap_off(ch * 8 + half * 4 + g4);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xb[half][pt] = *(const frag_t*)(Raw + xo + pt * rowb);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2 * NT; ++u) {
@@ -530,18 +563,18 @@ static hipError_t launch_rtile_dense5(const RTileParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int NT, int PT, bool BF16>
+template <int NT, int PT, bool BF16, bool D4 = false>
 static hipError_t launch_rtile_t(const RTileParams& p, hipStream_t st, int label) {
   const int lds = p.raw_bytes + p.nch * p.NP * 128;
   {
-    hipError_t e = ensure_max_lds((const void*)rtile_kernel<NT, PT, BF16>, 80 * 1024);
+    hipError_t e = ensure_max_lds((const void*)rtile_kernel<NT, PT, BF16, D4>, 80 * 1024);
     if (e != hipSuccess) return e;
   }
   const int tiles = p.B * p.ty * p.tx;
   const int grid = p.up2 ? class_tile_grid(tiles) : tiles;
   set_launch_grid(grid);
   ProfScope ps_(st, label);
-  hipLaunchKernelGGL((rtile_kernel<NT, PT, BF16>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((rtile_kernel<NT, PT, BF16, D4>), dim3(grid), dim3(256), lds, st, p);
   return hipGetLastError();
 }
 
@@ -557,6 +590,7 @@ hipError_t launch_rtile(const RTileParams& p, hipStream_t st) {
   if (p.dense == 3) return launch_rtile_dense5<3>(p, st);
   if (p.dense == 4) return launch_rtile_dense5<4>(p, st);
   if (p.dense == 5) return launch_rtile_dense5<5>(p, st);
+  if (p.dense == 204) return (p.bf16 && p.NP == 48) ? launch_rtile_t<3, 8, true, true>(p, st, PL_GCONV_N48) : hipErrorInvalidValue;   // bf16 pair-of-taps form
   if (p.dense) return hipErrorInvalidValue;
   if (p.NP == 48) return p.bf16 ? launch_rtile_t<3, 8, true>(p, st, PL_GCONV_N48) : launch_rtile_t<3, 2, false>(p, st, PL_GCONV_N48);
   if (p.NP == 32) return p.bf16 ? launch_rtile_t<2, 8, true>(p, st, PL_GCONV_N24) : launch_rtile_t<2, 2, false>(p, st, PL_GCONV_N24);
