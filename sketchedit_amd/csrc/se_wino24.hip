@@ -310,6 +310,9 @@ __global__ __launch_bounds__(512, 2) void wino24_kernel(const WinoParams p) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) wa[t] = *(const f32x4*)(Ww + t * 2048 + off0);
 
+  // (Round 5: a static s_setprio 1 for one half of the waves -- the second-dispatched half, MI355X_MICROARCH.md "two waves per
+  // SIMD" item 4, or the first -- measured on the same box: wino_n192 4.774-4.792 / 4.777-4.785 / 4.770-4.785 ms per step
+  // without / waves 4-7 / waves 0-3: no effect; the two waves of a SIMD here are symmetric partners, not a compute / load pair.)
   W24_STAMP_AT(72, 1);
   // stages x (chunk, j), fully unrolled through a compile-time index (72 bodies are beyond what `#pragma unroll` accepts):
   // everything below is compile-time
