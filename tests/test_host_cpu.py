@@ -475,3 +475,33 @@ def test_bench_all_cores_cpu_sample_is_bounded():
     assert time.perf_counter() - t0 < 40.0
     assert r["threads"] == (os.cpu_count() or 1) and "note" in r
     assert r["images_per_sec"] is None or r["images_per_sec"] > 0.0
+
+
+def test_developer_switches_are_a_table_read_once():
+    """The library's kernel-form switches: one process-wide table filled from the environment ONCE (no getenv on a launch
+    path), changed afterwards only through se_debug_set_option.  No device needed: the table lives on the host."""
+    import subprocess
+    import sys
+    assert _lib.get_option("SE_WINOGRAD_F43") == 1 and _lib.get_option("WINOGRAD_F43") == 1      # with or without the prefix
+    assert _lib.get_option("SE_ATT_FUSED") == -1 and _lib.get_option("SE_RTILE_WX") == 2
+    _lib.set_option("SE_WINOGRAD_F43", 2)
+    _lib.set_option("SE_TEST_OFFSET_LIMIT", 12345)
+    assert _lib.get_option("SE_WINOGRAD_F43") == 2 and _lib.get_option("SE_TEST_OFFSET_LIMIT") == 12345
+    os.environ["SE_WINOGRAD_F43"] = "0"                  # the environment is not consulted again
+    try:
+        assert _lib.get_option("SE_WINOGRAD_F43") == 2
+        _lib.reset_options()
+        assert _lib.get_option("SE_WINOGRAD_F43") == 1 and _lib.get_option("SE_TEST_OFFSET_LIMIT") == 0
+    finally:
+        del os.environ["SE_WINOGRAD_F43"]
+    with pytest.raises(_lib.SketchEditHipError):
+        _lib.set_option("SE_NO_SUCH_SWITCH", 1)
+    with pytest.raises(_lib.SketchEditHipError):
+        _lib.get_option("SE_WINOGRAD_F43_SKIP")           # removed in round 5
+    # a fresh process takes its initial values from the environment -- except the test aid, which only the call can set
+    code = ("from sketchedit_amd import _lib; print(_lib.get_option('SE_WINOGRAD_F43'), _lib.get_option('SE_ATT_E16'), "
+            "_lib.get_option('SE_TEST_OFFSET_LIMIT'))")
+    env = dict(os.environ, SE_WINOGRAD_F43="2", SE_ATT_E16="0", SE_TEST_OFFSET_LIMIT="777")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["2", "0", "0"]
