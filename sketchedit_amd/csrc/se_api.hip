@@ -204,6 +204,7 @@ int pack_wino24(se_ctx* c, Layer& L);
 int pack_rtilew(se_ctx* c, Layer& L);
 bool wino48_eligible_layer(const LayerDef& d);
 int pack_wino48(se_ctx* c, Layer& L);
+int pack_wino48_c24(se_ctx* c, Layer& L);
 bool winoup_eligible_layer(const LayerDef& d);
 int pack_winoup(se_ctx* c, Layer& L);
 bool winoup48_eligible_layer(const LayerDef& d);
@@ -300,6 +301,7 @@ int pack_layer(se_ctx* c, Layer& L, const std::vector<int>& cin_map) {
   if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 48 && d.cout == 192 && d.act != ACT_NONE && Cp == d.cin) return pack_wino24(c, L);      // xconv5
   if (d.k == 3 && d.stride == 1 && !d.up && d.rate == 1 && d.cin == 24 && d.cout == 24 && d.act != ACT_NONE && Cp == d.cin) return pack_rtilew(c, L);   // conv16
   if (wino48_eligible_layer(d) && Cp == d.cin) return pack_wino48(c, L);
+  if (d.k == 3 && d.stride == 1 && !d.up && d.cin == 24 && d.cout == 96 && d.act != ACT_NONE && Cp == d.cin) return pack_wino48_c24(c, L);   // xconv3, pmconv3
   if (winoup_eligible_layer(d) && Cp == d.cin) return pack_winoup(c, L);
   if (winoup48_eligible_layer(d) && Cp == d.cin) return pack_winoup48(c, L);
   return 0;
@@ -709,6 +711,40 @@ int pack_wino48(se_ctx* c, Layer& L) {
         const int s_ = kin / 4, e = kin % 4;
         const int ps = s_ ^ ((n >> 1) & 7);
         img[((size_t)it * NP + n) * 32 + ps * 4 + e] = u;
+      }
+    }
+  }
+  if (L.d_u) (void)hipFree(L.d_u);
+  if (L.d_ub) (void)hipFree(L.d_ub);
+  HIPCHK(c, hipMalloc(&L.d_u, img.size() * 4));
+  HIPCHK(c, hipMalloc(&L.d_ub, bias.size() * 4));
+  HIPCHK(c, hipMemcpy(L.d_u, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(L.d_ub, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// 24 -> 96 layers on the same kernel (se_wino48.hip, CIN = 24): one iteration per position, U[pos] as a [96 MIXED rows][32 k]
+// tile: channels 0-15 in slots 0-3, channels 16 + 2q, 17 + 2q in elements 0, 1 of slot 4 + q (k-half 1 issues two k-steps:
+// a k-step takes one element of every slot), elements 2, 3 zero.
+int pack_wino48_c24(se_ctx* c, Layer& L) {
+  const LayerDef& d = L.def;
+  static const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int NP = 96;
+  std::vector<float> img((size_t)16 * NP * 32, 0.f), bias(NP, 0.f);
+  for (int n = 0; n < NP; ++n) {
+    const int t = n / 16, r = n % 16;
+    const int oc = r < 8 ? t * 8 + r : 48 + t * 8 + (r - 8);
+    bias[n] = L.b[oc];
+    for (int ic = 0; ic < 24; ++ic) {
+      const float* g = &L.w[((size_t)oc * d.cin + ic) * 9];
+      float tt[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int kx = 0; kx < 3; ++kx) tt[i][kx] = Gm[i][0] * g[kx] + Gm[i][1] * g[3 + kx] + Gm[i][2] * g[6 + kx];
+      for (int pos = 0; pos < 16; ++pos) {
+        const int xi = pos >> 2, nu = pos & 3;
+        const float u = tt[xi][0] * Gm[nu][0] + tt[xi][1] * Gm[nu][1] + tt[xi][2] * Gm[nu][2];
+        const int s_ = ic < 16 ? ic / 4 : 4 + (ic - 16) / 2, e = ic < 16 ? ic % 4 : (ic - 16) % 2, ps = s_ ^ ((n >> 1) & 7);
+        img[((size_t)pos * NP + n) * 32 + ps * 4 + e] = u;
       }
     }
   }
@@ -1250,6 +1286,23 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
     set_launch_cost(alg, 4.0 * 2.0 * (double)B * Hin * Win * 48, d.name, alg * 16.0 / 36.0);
     HIPCHK(c, launch_wino48(wp, c->st));
+    return 0;
+  }
+  // 24 -> 96 (xconv3 / pmconv3 of netG) on the same kernel, one chunk per position (se_wino48.hip CIN = 24): 16 of 36 products
+  if (use_wino && use_wino48 && !d.up && L.d_u && L.d_ub && !src1 && C0 == 24 && d.cin == 24 && d.cout == 96 && d.stride == 1 &&
+      (long long)B * Hin * Win * 192 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+    WinoParams wp;
+    memset(&wp, 0, sizeof wp);
+    wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
+    wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = Win / 2;
+    wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
+    wp.xcd = xcd_remap_enabled();
+    udiv_magic_host((unsigned)(wp.th * wp.tw), &wp.div_tpi_m, &wp.div_tpi_l);
+    udiv_magic_host((unsigned)wp.tw, &wp.div_tw_m, &wp.div_tw_l);
+    udiv_magic_host((unsigned)wp.d, &wp.div_d_m, &wp.div_d_l);
+    const double alg = 2.0 * (double)B * Ho * Wo * d.cout * d.cin * 9;
+    set_launch_cost(alg, 4.0 * ((double)B * Hin * Win * 24 + (double)B * Hin * Win * 48), d.name, alg * 16.0 / 36.0);
+    HIPCHK(c, launch_wino48_c24(wp, c->st));
     return 0;
   }
   const bool use_winoup = opt(OPT_WINOGRAD_UP) != 0;

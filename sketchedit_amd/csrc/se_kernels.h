@@ -156,6 +156,9 @@ hipError_t launch_wino24(const WinoParams& p, hipStream_t st);
 hipError_t launch_wino24_c48(const WinoParams& p, hipStream_t st);
 // 48 -> 96 form (se_wino48.hip): src / dst NHWC 48 channels, upk [24 iterations][96 MIXED rows][32], bias [96] MIXED order
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st);
+// 24 -> 96 in the same kernel (round 5; xconv3 / pmconv3): src NHWC 24 channels, upk [16 positions][96 MIXED rows][32 k:
+// channels 0-23, then zeros] (pack_wino48_c24), one iteration per position, k-half 1 issues two k-steps
+hipError_t launch_wino48_c24(const WinoParams& p, hipStream_t st);
 // gen_deconv 96 -> 96 (48 gated), F(2x2,2x2) on the 4 sub-pixel classes (se_wino_up.hip): src NHWC 96 at (h, w), dst NHWC
 // 48 at (2h, 2w), upk [4 classes][27 iterations][96 MIXED rows][32], bias [96] MIXED order; h, w even; th = h/2, tw = w/2
 hipError_t launch_winoup(const WinoParams& p, hipStream_t st);

@@ -12,9 +12,19 @@
 //     se_wino.hip) and the same 24 + 96 accumulator registers.
 //   * One workgroup = 8 waves = 128 tiles; a lane stages TWO granules per iteration (same tile and slot in both
 //     k-halves), from two offset sets: one for the even, one for the odd position of the pair.
+//
+// CIN = 24 (round 5: xconv3 / pmconv3 of netG, 24 -> 96 at the 128x128 level -- editline_g.py:63,75 -- two launches of 195 us
+// on the direct gather-GEMM at 256x256 B=32).  K per position is 24 = six k-steps of 4: ONE chunk per position, k-half 0 =
+// channels 0-15 (four k-steps), k-half 1 = channels 16-23 in TWO k-steps.  A k-step r of the 16x16x4 MFMA takes element r of
+// all four 16-byte slots of a k-half, so the eight channels sit as elements 0, 1 of slots 4-7 (slot 4 + q: channels 16 + 2q,
+// 17 + 2q -- the layout of se_rtilew.hip): the staging lane q gathers 8 bytes instead of 16 for that half, and k-steps 2, 3
+// (elements 2, 3: never written, zero in the W image) are not issued.  16 iterations = 16 positions
+// of 36 MFMAs per wave (6 k-steps x 3 row tiles x 2 tile groups), every iteration starts a position (C = 0) and the previous
+// one is folded in front of it; the offset sets alternate by position parity.  Pipeline, rings, epilogue: unchanged.
 #include "se_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // Developer aid (-DSE_WINO_TRACE, tools/wino_trace.py): s_memtime stamps of block 0 / waves 0 and 4, kept in LDS.
 #ifdef SE_WINO_TRACE
@@ -46,11 +56,23 @@ extern "C" int se_debug_wino48_trace(unsigned long long* host_out) {
 
 namespace se {
 
-template <int TILES>
+// a compile-time loop index: `#pragma unroll` on a 24-body loop whose body tests it / 3 and it % 3 is only partly honoured
+// (measured: 8 bodies in a run-time loop of 3, every "compile-time" condition a branch or a select)
+template <int I, int N, typename F>
+DEVFN void static_for48(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for48<I + 1, N>(f);
+  }
+}
+
+template <int TILES, int CIN = 48>
 __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p) {
+  static_assert(CIN == 48 || CIN == 24, "48 -> 96 (position pairs over three chunks) or 24 -> 96 (one chunk per position)");
   constexpr int NTHR = TILES * 4, NWV = TILES / 16;      // one thread per staged granule; a wave per (row half, 32 tiles)
   constexpr int XB = TILES * 128, WB = 96 * 128;
-  constexpr int NIT = 24;              // 8 position pairs x 3 chunks
+  constexpr int NIT = CIN == 48 ? 24 : 16;               // 8 position pairs x 3 chunks | 16 positions
+  constexpr unsigned PSB = CIN * 4;                      // bytes per source pixel
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   char* Wb = smem + 3 * XB;
@@ -95,8 +117,8 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
-      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * 192u + (unsigned)sg * 16u) : (int)0x80000000;
-      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * 192 : (int)0x80000000;
+      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * PSB + (unsigned)sg * 16u) : (int)0x80000000;
+      Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * (int)PSB : (int)0x80000000;
     }
   }
   const unsigned lds_w = lds_addr_of(Wb);
@@ -113,16 +135,26 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
     o[set][2] = __builtin_elementwise_add_sat(yb, xa); o[set][3] = __builtin_elementwise_add_sat(yb, xb);
   };
   // k-half h of iteration it -> (position set, 16-channel group): see the chunk table in the header
-  auto half_set = [](int it, int h) { return (it % 3) * 2 + h >= 3 ? 1 : 0; };
-  auto half_grp = [](int it, int h) { return ((it % 3) * 2 + h) % 3; };
+  // (CIN = 24: iteration = position, set = its parity, k-half h = channel group h)
+  auto half_set = [](int it, int h) { return CIN == 48 ? ((it % 3) * 2 + h >= 3 ? 1 : 0) : (it & 1); };
+  auto half_grp = [](int it, int h) { return CIN == 48 ? ((it % 3) * 2 + h) % 3 : h; };
   // position whose granules k-half h of iteration `it` carries: pair it / 3, even or odd member
-  auto half_pos = [&](int it, int h) { return 2 * (it / 3) + half_set(it, h); };
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * 192u), 0x00020000);
+  auto half_pos = [&](int it, int h) { return CIN == 48 ? 2 * (it / 3) + half_set(it, h) : it; };
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((unsigned)p.B * (unsigned)p.h * (unsigned)p.w * PSB), 0x00020000);
   // one raw granule (pixel i of the 4 sources) of k-half h of iteration `it`: one vector-memory instruction
+  const unsigned adj8 = (unsigned)sg * 8u;      // CIN = 24, k-half 1: this lane's 8 bytes start at 64 + 8 sg, the offsets hold 16 sg
   auto load_x1 = [&](int it, f32x4 (&r)[2][4], int h, int i) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o[half_set(it, h)][i], half_grp(it, h) * 64, 0);
-    r[h][i] = __builtin_bit_cast(f32x4, t);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    if (CIN == 24 && h == 1) {
+      // (an "outside" offset stays outside: it is >= 2^31 + 16 sg, or the saturated 2^32 - 1; the source is < 2^30 bytes)
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs0, (int)(o[half_set(it, h)][i] - adj8), 64, 0);
+      r[h][i][0] = __uint_as_float(t[0]);
+      r[h][i][1] = __uint_as_float(t[1]);
+    } else {
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o[half_set(it, h)][i], half_grp(it, h) * 64, 0);
+      r[h][i] = __builtin_bit_cast(f32x4, t);
+    }
   };
   float negone = -1.f;
   asm volatile("" : "+v"(negone));      // opaque -1: a subtraction stays one packed fma (a plain - becomes 4 v_sub)
@@ -142,7 +174,9 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
   };
   auto write_x = [&](int it, int buf, const f32x4 (&r)[2][4]) {
     *(f32x4*)(xw0 + buf * XB) = signed_sum(r[0], half_pos(it, 0));
-    *(f32x4*)(xw1 + buf * XB) = signed_sum(r[1], half_pos(it, 1));
+    const f32x4 s1 = signed_sum(r[1], half_pos(it, 1));
+    if (CIN == 24) *(f32x2*)(xw1 + buf * XB) = (f32x2){s1[0], s1[1]};      // channels 16 + 2 sg, 17 + 2 sg: elements 0, 1 of slot 4 + sg
+    else *(f32x4*)(xw1 + buf * XB) = s1;
   };
   // W tile: 12 row blocks of 8 rows; wave w stages blocks w, w + NWV, ... (8 waves: 2 calls, 4 waves: 3 calls per tile)
   auto dma_w = [&](int it, int buf, int j) {
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
     write_x(0, 0, r);
     write_x(1, 1, r1);
   }
-  set_pos(0, 2);                       // even position of pair 1 (iteration 3 on)
+  set_pos(0, 2);                       // even position of pair 1 (iteration 3 on) | CIN = 24: position 2 (iteration 2)
   dma_wait_all();
   __syncthreads();
 #pragma unroll
@@ -235,14 +269,13 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
   for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + j * 2048 + off0);
 
   W48_STAMP_AT(24, 1);
-#pragma unroll
-  for (int pp = 0; pp < 8; ++pp)       // position pairs x chunks, fully unrolled: everything below is compile-time
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int it = pp * 3 + c;
-    const int b0 = it % 3, b1 = (it + 1) % 3, b2 = (it + 2) % 3;      // X ring
-    const int w0 = it % 4, w1 = (it + 1) % 4, w3 = (it + 3) % 4;      // W ring
-    const bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
+  // (position pairs x chunks | positions), fully unrolled through a compile-time index: everything below is compile-time
+  static_for48<0, NIT>([&](auto it_c) __attribute__((always_inline)) {
+    constexpr int it = decltype(it_c)::value;
+    constexpr int pp = CIN == 48 ? it / 3 : it, c = CIN == 48 ? it % 3 : 0;
+    constexpr int b0 = it % 3, b1 = (it + 1) % 3, b2 = (it + 2) % 3;      // X ring
+    constexpr int w0 = it % 4, w1 = (it + 1) % 4, w3 = (it + 3) % 4;      // W ring
+    constexpr bool more1 = it + 1 < NIT, more2 = it + 2 < NIT, more3 = it + 3 < NIT;
     f32x4 wb[3], xb[2];
     xb[0] = *(const f32x4*)(Xw + b0 * XB + off1);                  // k-half 1 fragments of this iteration
     xb[1] = *(const f32x4*)(Xw + b0 * XB + 2048 + off1);
@@ -261,8 +294,8 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
       __builtin_amdgcn_sched_barrier(0);
     };
     W48_STAMP(0);
-    if (c == 0 && it > 0) {              // chunk A: the odd position of the previous pair is complete
-      fold(2 * pp - 1);
+    if (c == 0 && it > 0) {              // chunk A: the odd position of the previous pair is complete | CIN = 24: the previous position
+      fold(CIN == 48 ? 2 * pp - 1 : it - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     group(wa, xa, 0, c == 0);
@@ -270,7 +303,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
     group(wa, xa, 2, false);
     group(wa, xa, 3, false);
     W48_STAMP(1);
-    if (c == 1) {                        // chunk B: the even position ends with k-half 0, the odd one starts
+    if (CIN == 48 && c == 1) {           // chunk B: the even position ends with k-half 0, the odd one starts
       fold(2 * pp);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -279,13 +312,17 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
       write_x(it + 2, b2, r);
     }
     // next use of a position set: even set after the last chunk-B write, odd set after the last chunk-C write
-    if (c == 2 && 2 * (pp + 2) < 16) set_pos(0, 2 * (pp + 2));
-    if (c == 0 && 2 * (pp + 1) + 1 < 16) set_pos(1, 2 * (pp + 1) + 1);
+    if (CIN == 48) {
+      if (c == 2 && 2 * (pp + 2) < 16) set_pos(0, 2 * (pp + 2));
+      if (c == 0 && 2 * (pp + 1) + 1 < 16) set_pos(1, 2 * (pp + 1) + 1);
+    } else if (it + 3 < NIT) {
+      set_pos((it + 3) & 1, it + 3);   // its previous holder (position it + 1) was loaded during iteration it - 2
+    }
     __builtin_amdgcn_sched_barrier(0);
     // vector-memory instructions spread over the MFMA groups (a burst from all 8 waves fills the CU's queue and
     // stalls the waves, MFMAs included, in front of it)
     W48_STAMP(2);
-    group(wb, xb, 0, c == 1);
+    group(wb, xb, 0, CIN == 48 && c == 1);
     if (more3) { dma_w(it + 3, w3, 0); load_x1(it + 3, r, 0, 0); load_x1(it + 3, r, 0, 1); }
     if (more1) {                                          // k-half 0 fragments of it+1 (published slots)
       xa[0] = *(const f32x4*)(Xw + b1 * XB + off0);
@@ -294,18 +331,24 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
       for (int j = 0; j < 3; ++j) wa[j] = *(const f32x4*)(Ww + w1 * WB + j * 2048 + off0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (CIN == 24 && more3) { dma_w(it + 3, w3, 1); load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); load_x1(it + 3, r, 1, 0); }
     group(wb, xb, 1, false);
-    if (more3) { dma_w(it + 3, w3, 1); load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
-    __builtin_amdgcn_sched_barrier(0);
-    group(wb, xb, 2, false);
-    if (more3) { if (NWV < 8) dma_w(it + 3, w3, 2); load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
-    __builtin_amdgcn_sched_barrier(0);
-    group(wb, xb, 3, false);
-    if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
+    if (CIN == 48) {
+      if (more3) { dma_w(it + 3, w3, 1); load_x1(it + 3, r, 0, 2); load_x1(it + 3, r, 0, 3); }
+      __builtin_amdgcn_sched_barrier(0);
+      group(wb, xb, 2, false);
+      if (more3) { if (NWV < 8) dma_w(it + 3, w3, 2); load_x1(it + 3, r, 1, 0); load_x1(it + 3, r, 1, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      group(wb, xb, 3, false);
+      if (more3) { load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3); }
+    } else if (more3) {                                   // (k-steps 2, 3 of k-half 1 carry no channels: not issued)
+      if (NWV < 8) dma_w(it + 3, w3, 2);
+      load_x1(it + 3, r, 1, 1); load_x1(it + 3, r, 1, 2); load_x1(it + 3, r, 1, 3);
+    }
     W48_STAMP(3);
     end_barrier();
     W48_STAMP(4);
-  }
+  });
   W48_STAMP_AT(24, 2);
   fold(15);
 
@@ -334,7 +377,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
           float2 ov;
           ov.x = act_fast(f0, eluw) * sigmoid_fast(g0);
           ov.y = act_fast(f1, eluw) * sigmoid_fast(g1);
-          if (t < p.total_tiles)
+          if (t < p.total_tiles)      // (dst: 48 gated channels = 192 bytes per pixel whatever CIN)
             *(float2*)((char*)p.dst + ((unsigned)((b * p.h + y0 + a * p.d) * p.w + x0 + bb * p.d) * 192u + (unsigned)c0 * 4u)) = ov;      // 32-bit offset: the launch guards the bytes
         }
     }
@@ -346,22 +389,24 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
 
 // 64 tiles / 4 waves / 80 KB per workgroup (default): two workgroups share a CU, one's prologue, fold and epilogue run
 // under the other's MFMAs.  SE_WINO48_TILES=128 selects the 8-wave, one-workgroup-per-CU shape of round 1.
-template <int TILES>
+template <int TILES, int CIN = 48>
 static hipError_t launch_wino48_t(const WinoParams& p, hipStream_t st) {
   constexpr int LDS = 3 * TILES * 128 + 4 * 96 * 128 + 8 * TILES * 4 * 4 + (W48_TRACE_LDS ? 2 * 48 * 8 * 8 : 0);     // X ring + W ring 48 KB + source offsets
   {
-    hipError_t e = ensure_max_lds((const void*)wino48_kernel<TILES>, LDS);
+    hipError_t e = ensure_max_lds((const void*)wino48_kernel<TILES, CIN>, LDS);
     if (e != hipSuccess) return e;
   }
   const int grid = (p.total_tiles + TILES - 1) / TILES;
   set_launch_grid(grid);
   ProfScope ps_(st, PL_WINO_N96);
-  hipLaunchKernelGGL(wino48_kernel<TILES>, dim3(grid), dim3(TILES * 4), LDS, st, p);
+  hipLaunchKernelGGL((wino48_kernel<TILES, CIN>), dim3(grid), dim3(TILES * 4), LDS, st, p);
   return hipGetLastError();
 }
 hipError_t launch_wino48(const WinoParams& p, hipStream_t st) {
   const bool big = W48_TRACE_LDS || opt(OPT_WINO48_TILES) == 128;
   return big ? launch_wino48_t<128>(p, st) : launch_wino48_t<64>(p, st);
 }
+// 24 -> 96 (src NHWC 24 channels; upk [16 positions][96 MIXED rows][32 k: channels 0-23, then zeros], pack_wino48 with cin 24)
+hipError_t launch_wino48_c24(const WinoParams& p, hipStream_t st) { return launch_wino48_t<64, 24>(p, st); }
 
 }  // namespace se

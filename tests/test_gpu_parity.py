@@ -220,6 +220,28 @@ def test_op_winograd48_path_vs_oracle(eng, case):
     assert _md(y, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("case", WINO48, ids=["d%d-%dx%d-%s" % c for c in WINO48])
+def test_op_winograd24_to_96_path_vs_oracle(eng, case, seopt):
+    """24 -> 96 3x3 stride 1 (xconv3 / pmconv3 of netG, editline_g.py:63,75) on the 48-channel Winograd kernel's CIN = 24
+    form (round 5): one 32-k chunk per position whose k-half 1 carries channels 16-23 in two k-steps.  Ragged tile counts,
+    dilations, both activations; against the oracle and against the direct gather-GEMM (SE_WINOGRAD48=0), which must have
+    been a different kernel."""
+    from oracle import sketchedit_oracle as O
+    d, H, W, act = case
+    a = 1.5 / np.sqrt(24 * 9)
+    w = synth.uniform(18, "wino24c.w%s" % (case,), (96, 24, 3, 3), -a, a)
+    b = synth.uniform(18, "wino24c.b%s" % (case,), (96,), -0.3, 0.3)
+    x = synth.uniform(18, "wino24c.x%s" % (case,), (3, 24, H, W), -1, 1)
+    y = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
+    ref = O.gated_conv(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, d, act)
+    assert _md(y, ref) < TOL_OP
+    seopt.set("SE_WINOGRAD48", 0)
+    yd = eng.gated_conv2d(_cuda(x), w, b, stride=1, rate=d, act=act)
+    assert _md(yd, ref) < TOL_OP
+    if H % (2 * d) == 0 and W % (2 * d) == 0:
+        assert 0.0 < _md(y, yd) < 2e-5                  # (different kernels ran)
+
+
 WINOUP = [(8, 8, "elu"), (16, 24, "elu"), (64, 64, "elu"), (10, 14, "relu"), (34, 30, "elu"), (2, 2, "elu")]
 
 
