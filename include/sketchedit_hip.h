@@ -57,7 +57,16 @@ enum {
    * pipe (v_mfma_f32_16x16x32_bf16) with fp32 accumulation; bias, activations, gate, softmax and composites stay
    * fp32; the external tensors stay fp32 NCHW.  The comparator is the oracle's bf16 mode (oracle/sketchedit_oracle.py);
    * the 1e-3 fp32 bound of the north star does not apply (stated tolerances: tests/test_gpu_bf16.py). */
-  SE_FLAG_BF16 = 256
+  SE_FLAG_BF16 = 256,
+  /* CONSERVATIVE (fp32 mode; no reference counterpart): the precision choice for netM, whose soft mask feeds the hard 0.5
+   * threshold (editline2_model.py:346-347).  By default the 96->192 3x3 layers of BOTH nets run the hybrid Winograd
+   * F(2,3)xF(4,3) form; with this flag netM's run F(2x2,3x3) (dyadic transforms, error like the direct form) and only netG
+   * keeps the hybrid.  Measured over 72 images / 4.7 M mask pixels of the three procedural weight sets
+   * (profiles/r05_f43_flips.json): hard-mask pixels that differ from the fp32 CPU reference 4 (default) vs 1 (this flag;
+   * the direct form also has 1), soft-mask max-abs 2.6e-5 vs 1.6e-5, for +1.7 % per step (11.10 -> 11.29 ms at 256x256
+   * batch 32).  A caller with a real checkpoint whose logits cluster at the threshold sets it; honoured by se_inference,
+   * se_inference_u8, se_netM_forward_ex.  INTEGRATION.md "Precision choice". */
+  SE_FLAG_CONSERVATIVE = 512
 };
 
 /* replaces networks.create_network's .cuda() (models/networks/__init__.py:30-38) */
@@ -81,7 +90,7 @@ size_t se_workspace_bytes(se_ctx* ctx, int B, int H, int W);
 int se_netM_forward(se_ctx* ctx, void* stream, const float* image, const float* sketch, float* mask_out,
                     float* maskim_out, void* workspace, size_t workspace_bytes, int B, int H, int W);
 
-/* the same with execution options (SE_FLAG_LOW_LATENCY, SE_FLAG_BF16) */
+/* the same with execution options (SE_FLAG_LOW_LATENCY, SE_FLAG_BF16, SE_FLAG_CONSERVATIVE) */
 int se_netM_forward_ex(se_ctx* ctx, void* stream, const float* image, const float* sketch, float* mask_out,
                        float* maskim_out, void* workspace, size_t workspace_bytes, int B, int H, int W, int exec_flags);
 
@@ -90,6 +99,20 @@ int se_netM_forward_ex(se_ctx* ctx, void* stream, const float* image, const floa
 int se_netG_forward(se_ctx* ctx, void* stream, const float* x, const float* x2, const float* mask,
                     const float* mask2, const float* guide, float* coarse_out, float* fine_out, void* workspace,
                     size_t workspace_bytes, int B, int H, int W, int flags);
+
+/* netG with optional intermediate outputs ("taps"; test support -- the reference's counterparts are forward hooks on
+ * netG.pmconv6 / netG.cam_2 / netG.conv11, tests/golden/make_golden.py).  Any pointer may be NULL; taps == NULL is
+ * se_netG_forward.  The tensors are written by the SAME launches that feed the next layer of the production plan (the
+ * attention runs in whatever form the forward would use), so a test sees what the forward computed, in the reference's
+ * NCHW fp32 layout.  One pass only: B must fit the 32-bit offset range (341 images at 256x256). */
+typedef struct se_netG_taps {
+  float* pmconv6;   /* (B,96,H/4,W/4)  output of pmconv6 = input of the attention   editline_g.py:202 */
+  float* attn_out;  /* (B,96,H/4,W/4)  output of cam_2                              editline_g.py:203-207 */
+  float* style_vec; /* (B,96)          pooled style vector fed to conv11            editline_g.py:159-167 */
+} se_netG_taps;
+int se_netG_forward_taps(se_ctx* ctx, void* stream, const float* x, const float* x2, const float* mask,
+                         const float* mask2, const float* guide, float* coarse_out, float* fine_out, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int flags, const se_netG_taps* taps);
 
 /* EditLine2Model.forward(mode='inference') (editline2_model.py:128-133 + generate_fake :338-370):
  * netM -> (mask > 0.5) -> netG -> composed = fine*mask + image*(1-mask) with the SOFT mask.

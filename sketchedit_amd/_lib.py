@@ -20,20 +20,25 @@ SOURCES = ["se_gconv.hip", "se_rconv16.hip", "se_rconv96.hip", "se_rtile.hip", "
 
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
-FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT, FLAG_BF16 = 32, 64, 128, 256   # execution options (include/sketchedit_hip.h)
+FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT, FLAG_BF16, FLAG_CONSERVATIVE = 32, 64, 128, 256, 512   # execution options (include/sketchedit_hip.h)
 # calls of at most this many pixels (four 256x256 images, one 512x512) run in the low-latency mode unless the caller says
 # otherwise: measured on MI355X, 4 x 256x256 3.59 ms vs 4.55 ms, 1 x 512x512 3.75 ms vs 5.09 ms (low-latency vs default)
 LOW_LATENCY_MAX_PIXELS = 4 * 256 * 256
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
-           "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_inference", "se_inference_u8", "se_gated_conv2d",
+           "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_netG_forward_taps", "se_inference", "se_inference_u8", "se_gated_conv2d",
            "se_gated_conv2d_ex", "se_attention", "se_attention_ex", "se_quantize_u8", "se_profile_enable",
            "se_profile_report", "se_debug_set_option", "se_debug_get_option", "se_debug_reset_options"]
 
 
 class SketchEditHipError(RuntimeError):
     pass
+
+
+class NetGTaps(ctypes.Structure):
+    """se_netG_taps (include/sketchedit_hip.h): optional intermediate outputs of netG, device pointers or NULL"""
+    _fields_ = [("pmconv6", ctypes.c_void_p), ("attn_out", ctypes.c_void_p), ("style_vec", ctypes.c_void_p)]
 
 
 def build_library(force=False, verbose=False, extra_flags=()):
@@ -117,6 +122,8 @@ def load_library():
         lib.se_netM_forward_ex.restype = ci
         lib.se_netG_forward.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
         lib.se_netG_forward.restype = ci
+        lib.se_netG_forward_taps.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci, ctypes.POINTER(NetGTaps)]
+        lib.se_netG_forward_taps.restype = ci
         lib.se_inference.argtypes = [vp, vp, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, vp, sz, ci, ci, ci, ci]
         lib.se_inference.restype = ci
         lib.se_inference_u8.argtypes = [vp, vp, c_f, c_f, vp, vp, vp, sz, ci, ci, ci, ci]
@@ -225,6 +232,7 @@ class Engine:
         self._ws_stream = None
         self._graph_stream = None
         self.precision = "f32"     # "bf16": BASELINE config 5 (bf16 storage + MFMA, fp32 accumulate); see set_precision
+        self.conservative = False  # SE_FLAG_CONSERVATIVE on every forward: netM's 96 -> 192 layers on F(2x2,3x3) (set_conservative)
         self._static = {}          # graph mode: per-shape input copies and output buffers (stable pointers)
         self._graph_lock = threading.Lock()    # graph mode is single-caller per Engine: one replay at a time
 
@@ -291,7 +299,8 @@ class Engine:
         mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=image.device)
         mim = torch.empty((B, 3, H, W), dtype=torch.float32, device=image.device) if want_image else None
         if self.lib.se_netM_forward_ex(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(mask), _ptr(mim),
-                                       _ptr(ws), ws.numel(), B, H, W, FLAG_BF16 if self.precision == "bf16" else 0):
+                                       _ptr(ws), ws.numel(), B, H, W,
+                                       (FLAG_BF16 if self.precision == "bf16" else 0) | (FLAG_CONSERVATIVE if self.conservative else 0)):
             self._err("se_netM_forward_ex")
         return mask, mim
 
@@ -308,6 +317,30 @@ class Engine:
             self._err("se_netG_forward")
         return coarse, fine
 
+    def netG_taps(self, x, x2, mask, mask2, guide, flags):
+        """netG with its intermediate outputs (se_netG_forward_taps; the counterparts of the forward hooks
+        tests/golden/make_golden.py puts on the reference): -> dict(coarse, fine, pmconv6, attn_out, style_vec).  The
+        attention runs in the form the production forward uses."""
+        import torch
+        _check_dev(x, x2, mask, mask2, guide)
+        B, _, H, W = x.shape
+        ws = self.workspace(B, H, W)
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)     # noqa: E731
+        r = dict(coarse=mk(B, 3, H, W), fine=mk(B, 3, H, W), pmconv6=mk(B, 96, H // 4, W // 4), style_vec=mk(B, 96))
+        if flags & FLAG_USE_CAM:
+            r["attn_out"] = mk(B, 96, H // 4, W // 4)
+        taps = NetGTaps(r["pmconv6"].data_ptr(), r["attn_out"].data_ptr() if "attn_out" in r else None, r["style_vec"].data_ptr())
+        flags = (flags & 31) | (FLAG_BF16 if self.precision == "bf16" else 0)
+        if self.lib.se_netG_forward_taps(self.h, self._stream(), _ptr(x), _ptr(x2), _ptr(mask), _ptr(mask2), _ptr(guide),
+                                         _ptr(r["coarse"]), _ptr(r["fine"]), _ptr(ws), ws.numel(), B, H, W, flags, ctypes.byref(taps)):
+            self._err("se_netG_forward_taps")
+        return r
+
+    def set_conservative(self, on=True):
+        """SE_FLAG_CONSERVATIVE (include/sketchedit_hip.h): netM -- whose soft mask feeds the hard 0.5 threshold -- keeps the
+        F(2x2,3x3) Winograd form; netG keeps the hybrid one.  +1.7 % per step at 256x256 batch 32."""
+        self.conservative = bool(on)
+
     def set_precision(self, precision):
         """'f32' (default; the north star's 1e-3 parity bound applies) or 'bf16' (SE_FLAG_BF16 on every forward)."""
         if precision not in ("f32", "bf16"):
@@ -322,7 +355,7 @@ class Engine:
     def exec_flags(self, B, H, W, low_latency=None, graph=False):
         """Execution-option bits for a call."""
         return (FLAG_LOW_LATENCY if self.is_low_latency(B, H, W, low_latency) else 0) | (FLAG_GRAPH if graph else 0) | \
-            (FLAG_BF16 if self.precision == "bf16" else 0)
+            (FLAG_BF16 if self.precision == "bf16" else 0) | (FLAG_CONSERVATIVE if self.conservative else 0)
 
     def inference(self, image, sketch, flags, visualize=False, out=None, low_latency=None, graph=False):
         """-> dict(composed, mask[, hard, maskim, coarse, fine]).  `out` may hold preallocated composed/mask.

@@ -156,6 +156,8 @@ struct se_ctx {
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
   int cur_net = SE_NET_G;   // network whose plan is running (plan_netM / plan_netG; per-op entry points: G)
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
+  bool conservative = false;       // SE_FLAG_CONSERVATIVE of the running call: netM's 96 -> 192 layers on F(2x2,3x3)
+  const se_netG_taps* taps = nullptr;      // se_netG_forward_taps: intermediate outputs of the running netG plan
   float* vbias_ws = nullptr;       // [B][9][192] scratch for the folded vector source of the next two-source layer (plan_netG)
   const float* vec32 = nullptr;    // bf16 mode: the fp32 copy of the vector source (the conv source itself is its bf16 rounding)
   unsigned char* rgb8 = nullptr;   // se_inference_u8: uint8 outputs written by the last kernel of the running call
@@ -1231,7 +1233,9 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
     // rule VERDICT r4 set (switch only if it costs < 1 %) the default stays 1.  (A mode that kept F(2x2,3x3) for netM's mask
     // decoder alone was measured too: 4 flips, no better than mode 1 -- the error comes from the encoder; removed.)
     const int f43_mode = opt(OPT_WINOGRAD_F43);
-    const bool f43 = (f43_mode == 1 || (f43_mode == 2 && c->cur_net == SE_NET_G)) && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
+    // SE_FLAG_CONSERVATIVE is mode 2 for this call, chosen by the caller through the ABI instead of the process-wide table
+    const bool f43_net_ok = c->cur_net == SE_NET_G || (f43_mode == 1 && !c->conservative);
+    const bool f43 = (f43_mode == 1 || f43_mode == 2) && f43_net_ok && (wp.src1 ? (!wp.src1_vec && L.d_u24b) : L.d_u24 != nullptr) && L.d_ub24 && (Win % (4 * d.rate)) == 0;
     wp.B = B; wp.h = Hin; wp.w = Win; wp.d = d.rate; wp.th = Hin / 2; wp.tw = f43 ? Win / 4 : Win / 2;
     wp.total_tiles = B * wp.th * wp.tw; wp.act = d.act;
     wp.xcd = xcd_remap_enabled();
@@ -1567,6 +1571,8 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   if (!c->dry)
     HIPCHK(c, launch_colreduce(xs.p, part.p, c->bf16 ? vec32.p : vec.p, B, xs.H * xs.W, 96, (flags & SE_FLAG_POOL_MAX) ? 0 : 1,
                                c->st, c->bf16 ? 1 : 0, c->bf16 ? vec.p : nullptr));
+  if (!c->dry && c->taps && c->taps->style_vec)
+    HIPCHK(c, hipMemcpyAsync(c->taps->style_vec, c->bf16 ? vec32.p : vec.p, (size_t)B * 96 * 4, hipMemcpyDeviceToDevice, c->st));
   P.free(xs);
   P.free(part);
   if (!c->bf16) P.free(vec32);        // bf16 mode: the fp32 vector feeds the bias table of conv11 (released after the decoder)
@@ -1596,12 +1602,17 @@ int plan_netG(se_ctx* c, const float* x, const float* x2, const float* mask, con
   pm = P.conv("pmconv4_downsample", pm);
   pm = P.conv("pmconv5", pm);
   pm = P.conv("pmconv6", pm);
+  if (P.rc) return P.rc;
+  if (!c->dry && c->taps && c->taps->pmconv6)
+    HIPCHK(c, (c->bf16 ? launch_nhwc16_to_nchw : launch_nhwc_to_nchw)(pm.p, c->taps->pmconv6, B, 96, 96, pm.H, pm.W, c->st));
   if (flags & SE_FLAG_USE_CAM) {
     Act att = P.alloc(pm.H, pm.W, 96);
     if (P.rc) return P.rc;
     if (run_attention(c, P, pm, mask, att, nullptr)) return P.rc ? P.rc : 1;
     P.free(pm);
     pm = att;
+    if (!c->dry && c->taps && c->taps->attn_out)
+      HIPCHK(c, (c->bf16 ? launch_nhwc16_to_nchw : launch_nhwc_to_nchw)(pm.p, c->taps->attn_out, B, 96, 96, pm.H, pm.W, c->st));
   }
   pm = P.conv("pmconv9", pm);
   pm = P.conv("pmconv10", pm);
@@ -1720,7 +1731,7 @@ int pass_size(se_ctx* c, int B, int H, int W, int flags) {
 se_ctx::Peaks plan_peaks(se_ctx* c, int which, int B, int H, int W, int flags, bool want_maskim) {
   const std::vector<long long> key = {which, B, H, W,
                                       flags & (SE_FLAG_USE_CAM | SE_FLAG_JOINT_TRAIN_INP | SE_FLAG_LOW_LATENCY | SE_FLAG_BF16),
-                                      want_maskim ? 1 : 0, attention_v2_enabled() ? 1 : 0};
+                                      want_maskim ? 1 : 0, attention_v2_enabled() ? 1 : 0, opt_epoch()};
   auto it = c->peaks.find(key);
   if (it != c->peaks.end()) return it->second;
   const bool dry0 = c->dry, ll0 = c->low_latency, bf0 = c->bf16;
@@ -1760,6 +1771,8 @@ void begin_call(se_ctx* c, void* stream, int flags) {
   c->dry = false;
   c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
   c->bf16 = (flags & SE_FLAG_BF16) != 0;
+  c->conservative = (flags & SE_FLAG_CONSERVATIVE) != 0;
+  c->taps = nullptr;
   c->rgb8 = nullptr; c->m8 = nullptr;
   c->cur_net = SE_NET_G;       // per-op entry points run as netG layers whatever plan ran last; the plans set their own
   set_profiler(&c->prof);
@@ -1947,7 +1960,7 @@ int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float*
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
-  exec_flags &= SE_FLAG_LOW_LATENCY | SE_FLAG_BF16;
+  exec_flags &= SE_FLAG_LOW_LATENCY | SE_FLAG_BF16 | SE_FLAG_CONSERVATIVE;
   const int nb = pass_size(c, B, H, W, exec_flags);
   if (!nb) return 1;
   const size_t HW = (size_t)H * W;
@@ -1967,9 +1980,9 @@ int se_netM_forward(se_ctx* c, void* stream, const float* image, const float* sk
   return se_netM_forward_ex(c, stream, image, sketch, mask_out, maskim_out, ws, ws_bytes, B, H, W, 0);
 }
 
-int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, const float* mask, const float* mask2,
-                    const float* guide, float* coarse_out, float* fine_out, void* ws, size_t ws_bytes, int B, int H,
-                    int W, int flags) {
+int se_netG_forward_taps(se_ctx* c, void* stream, const float* x, const float* x2, const float* mask, const float* mask2,
+                         const float* guide, float* coarse_out, float* fine_out, void* ws, size_t ws_bytes, int B, int H,
+                         int W, int flags, const se_netG_taps* taps) {
   if (!c) return 1;
   std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 1;
@@ -1977,16 +1990,25 @@ int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, co
   HIPCHK(c, hipSetDevice(c->device));
   const int nb = pass_size(c, B, H, W, flags);
   if (!nb) return 1;
+  if (taps && nb < B) return fail(c, "se_netG_forward_taps: %d images do not fit one pass (%d)", B, nb);
   const size_t HW = (size_t)H * W;
   for (int b0 = 0; b0 < B; b0 += nb) {
     const int bb = std::min(nb, B - b0);
     if (carve(c, plan_peaks(c, 2, bb, H, W, flags, false), ws, ws_bytes, 0)) return 1;
     begin_call(c, stream, flags);
+    c->taps = taps;
     const int rc = plan_netG(c, x + b0 * 3 * HW, x2 + b0 * 3 * HW, mask + b0 * HW, mask2 + b0 * HW, guide + b0 * HW,
                              coarse_out ? coarse_out + b0 * 3 * HW : nullptr, fine_out + b0 * 3 * HW, nullptr, nullptr, bb, H, W, flags);
+    c->taps = nullptr;
     if (rc) return rc;
   }
   return 0;
+}
+
+int se_netG_forward(se_ctx* c, void* stream, const float* x, const float* x2, const float* mask, const float* mask2,
+                    const float* guide, float* coarse_out, float* fine_out, void* ws, size_t ws_bytes, int B, int H,
+                    int W, int flags) {
+  return se_netG_forward_taps(c, stream, x, x2, mask, mask2, guide, coarse_out, fine_out, ws, ws_bytes, B, H, W, flags, nullptr);
 }
 
 namespace {
@@ -2042,7 +2064,7 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   const std::vector<long long> key = {(long long)(size_t)image, (long long)(size_t)sketch, (long long)(size_t)composed_out,
                                       (long long)(size_t)mask_out, (long long)(size_t)hard_out, (long long)(size_t)maskim_out,
                                       (long long)(size_t)coarse_out, (long long)(size_t)fine_out, (long long)(size_t)ws,
-                                      (long long)ws_bytes, B, H, W, flags};
+                                      (long long)ws_bytes, B, H, W, flags, opt_epoch()};
   se_ctx::GraphEntry* ge = nullptr;
   for (auto& g : c->graphs)
     if (g.key == key) { ge = &g; break; }

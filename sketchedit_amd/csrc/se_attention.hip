@@ -1593,8 +1593,10 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
     }
   }
   {
-    set_launch_cost(2.0 * p.B * (double)p.L * p.L * 1536.0, (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96, nullptr,
-                    2.0 * p.B * (double)p.R * p.R * 384.0);
+    // executed FLOPs = the tiles really launched x (PT*64 queries x NT*16 keys x K = 384): the symmetric enumeration runs
+    // symT = 32 np^2 + 8 np of the 64 np^2 tiles (booking R*R regardless of p.sym printed a rate above the peak)
+    const double alg_flops = 2.0 * p.B * (double)p.L * p.L * 1536.0;
+    const double alg_bytes = (BF16 ? 2.0 : 4.0) * 2.0 * p.B * (double)p.h * p.w * 96;
     const long big_grid = (long)((p.R + 255) / 256) * ((p.R + 63) / 64) * p.B;
     if (big_grid >= 512) {
       constexpr int NT = 4, PT = 4;
@@ -1610,6 +1612,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
         p.symT = 32 * np * np + 8 * np;
         grid = dim3((unsigned)(p.symT * p.B));
       }
+      set_launch_cost(alg_flops, alg_bytes, nullptr, 2.0 * (double)grid.x * grid.y * grid.z * (PT * 64.0) * (NT * 16.0) * 384.0);
       set_launch_grid((long)grid.x * grid.y * grid.z);
       ProfScope ps_(st, PL_ATT_SCORE);
       hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);
@@ -1627,6 +1630,7 @@ static hipError_t launch_attention_v2_t(const AttParams& p0, hipStream_t st) {
         p.symT = 32 * np * np + 8 * np;
         grid = dim3((unsigned)(p.symT * p.B));
       }
+      set_launch_cost(alg_flops, alg_bytes, nullptr, 2.0 * (double)grid.x * grid.y * grid.z * (PT * 64.0) * (NT * 16.0) * 384.0);
       set_launch_grid((long)grid.x * grid.y * grid.z);
       ProfScope ps_(st, PL_ATT_SCORE);
       hipLaunchKernelGGL((att2_pair_kernel<NT, PT, BF16>), grid, dim3(256), LDS, st, p);

@@ -65,6 +65,7 @@ int opt(int o);                                   // current value
 int opt_set(const char* name, int value);         // "SE_<NAME>" or "<NAME>"; returns 0, or 1 for an unknown name
 int opt_get(const char* name, int* value);        // the same for reading
 void opt_reset();                                 // every entry back to its environment / built-in default
+long long opt_epoch();                            // number of opt_set / opt_reset calls so far (key of captured forwards)
 
 // ---------------------------------------------------------------------------------------------
 // Gather-GEMM gated convolution (the hot kernel).

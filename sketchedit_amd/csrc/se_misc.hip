@@ -55,10 +55,15 @@ OptTable& opt_table() {
 }
 }  // namespace
 int opt(int o) { return opt_table().v[o].load(std::memory_order_relaxed); }
+// bumped by every change of the table: part of the key of a captured forward (SE_FLAG_GRAPH), so that a graph captured under
+// one set of kernel forms is never replayed after the forms were switched
+static std::atomic<long long> g_opt_epoch{0};
+long long opt_epoch() { return g_opt_epoch.load(std::memory_order_relaxed); }
 int opt_set(const char* name, int value) {
   const int i = OptTable::index_of(name);
   if (i < 0) return 1;
   opt_table().v[i].store(value, std::memory_order_relaxed);
+  g_opt_epoch.fetch_add(1, std::memory_order_relaxed);
   return 0;
 }
 int opt_get(const char* name, int* value) {
@@ -70,6 +75,7 @@ int opt_get(const char* name, int* value) {
 void opt_reset() {
   OptTable& t = opt_table();
   for (int i = 0; i < OPT_COUNT; ++i) t.v[i].store(t.dflt[i], std::memory_order_relaxed);
+  g_opt_epoch.fetch_add(1, std::memory_order_relaxed);
 }
 
 // ---- profiler plumbing ----------------------------------------------------------------------------

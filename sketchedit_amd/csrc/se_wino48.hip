@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = y0 + (i - 1) * p.d, x = x0 + (i - 1) * p.d;
-      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * PSB + (unsigned)sg * 16u) : (int)0x80000000;
+      Ysrc[i * NTHR + tid] = (t < p.total_tiles && (unsigned)y < (unsigned)p.h) ? (int)((unsigned)((b * p.h + y) * p.w) * PSB + (unsigned)sg * 16u) : (int)(0x80000000u + (unsigned)sg * 16u);
       Xsrc[i * NTHR + tid] = ((unsigned)x < (unsigned)p.w) ? x * (int)PSB : (int)0x80000000;
     }
   }
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(TILES * 4, 2) void wino48_kernel(const WinoParams p
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     if (CIN == 24 && h == 1) {
-      // (an "outside" offset stays outside: it is >= 2^31 + 16 sg, or the saturated 2^32 - 1; the source is < 2^30 bytes)
+      // (an "outside" offset stays outside after the subtraction: the row sentinel carries the lane's 16 sg like an in-image
+      // row offset does, so o >= 2^31 + 16 sg, or the saturated 2^32 - 1 -- independent of the host's size guard)
       const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs0, (int)(o[half_set(it, h)][i] - adj8), 64, 0);
       r[h][i][0] = __uint_as_float(t[0]);
       r[h][i][1] = __uint_as_float(t[1]);

@@ -19,6 +19,10 @@ class EditLine2Model(torch.nn.Module):
     @staticmethod
     def modify_commandline_options(parser, is_train):
         networks.modify_commandline_options(parser, is_train)
+        # no reference counterpart: SE_FLAG_CONSERVATIVE of the C-ABI (include/sketchedit_hip.h, INTEGRATION.md "Precision
+        # choice") -- the mask predictor on the F(2x2,3x3) Winograd form; for checkpoints whose mask logits sit at 0.5
+        parser.add_argument("--conservative_mask", action="store_true",
+                            help="netM on the conservative Winograd form (fewer hard-mask flips vs the fp32 CPU reference, +1.7 %% time)")
         return parser
 
     def __init__(self, opt):
@@ -52,6 +56,7 @@ class EditLine2Model(torch.nn.Module):
                                           "--gpu_ids -1 CPU mode has no counterpart here")
         if self._engine is None:
             self._engine = _lib.Engine(self.opt.gpu_ids[0])
+            self._engine.set_conservative(getattr(self.opt, "conservative_mask", False))
             self.netG.bind_engine(self._engine)
             self.netM.bind_engine(self._engine)
         self.netG.engine()                                # (re)upload weights if they changed

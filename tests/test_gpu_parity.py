@@ -549,6 +549,102 @@ def test_op_attention_all_invalid(eng):
     assert _md(out, ro) < TOL_OP
 
 
+@pytest.mark.parametrize("form", ["default", "fused", "three-pass", "all-tiles"])
+def test_op_attention_threshold_boundary_golden(eng, golden_dir, form, seopt):
+    """The key-validity boundary (key windows with exactly 24 / 25 / 26 / 27 non-hole pixels of 256 around th = 0.1,
+    /root/reference/models/networks/splitcam.py:49-53,90) against vectors of the REFERENCE's cam_1 / cam_2 modules
+    (tests/golden/make_golden.py --round6, ops_r6.npz).  Soft scores: a key on the wrong side of the threshold moves
+    `similar` by 0.26.  Every form of the HIP attention: the production choice, the fused streaming passes forced on, the
+    three-pass form, the all-tiles score GEMM."""
+    g = _load(golden_dir, "ops_r6.npz")
+    x = 0.004 * synth.uniform(11, "att_th.x", (2, 96, 12, 16), -1, 1)
+    full = np.unpackbits(g["op.att_th.mask_bits"])[: 2 * 48 * 64].reshape(2, 1, 48, 64).astype(np.float32)
+    if form == "fused":
+        seopt.set("SE_ATT_FUSED", 1)
+    elif form == "three-pass":
+        seopt.set("SE_ATT_FUSED", 0)
+    elif form == "all-tiles":
+        seopt.set("SE_ATT_SYM", 0)
+    out = eng.attention(_cuda(x), _cuda(full))                              # (similar_out forces the three-pass form)
+    assert _md(out, g["op.att_th.out"]) < 1e-5 * float(np.abs(g["op.att_th.out"]).max()) + 1e-7
+    out2, sim = eng.attention(_cuda(x), _cuda(full), want_similar=True)
+    assert _md(sim, g["op.att_th.similar"]) < 2e-6
+    assert _md(out2, g["op.att_th.out"]) < 1e-5 * float(np.abs(g["op.att_th.out"]).max()) + 1e-7
+
+
+def test_netG_intermediates_64_golden(eng_w, golden_dir):
+    """The reference-held intermediates of e2e_64.npz (forward hooks on netG.conv11 / cam_1 / cam_2 of the reference,
+    tests/golden/make_golden.py run_case) against the HIP path's own intermediates (se_netG_forward_taps): the pooled style
+    vector, the attention output as the PRODUCTION forward computes it, and `similar` from the HIP attention run on the HIP
+    pmconv6 output.  netG is fed the reference's hard mask."""
+    from oracle import sketchedit_oracle as O
+    g = _load(golden_dir, "e2e_64.npz")
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    hard = _cuda(g["hard_mask"])
+    ci, cs = _cuda(img), _cuda(sk)
+    r = eng_w.netG_taps(ci, ci, hard, hard, cs, FLAGS)
+    assert _md(r["coarse"], g["coarse"]) < TOL_E2E and _md(r["fine"], g["fine"]) < TOL_E2E
+    assert _md(r["style_vec"], g["style_vec"]) < 1e-4
+    assert _md(r["attn_out"], g["attn_out"]) < 1e-4 * max(1.0, float(np.abs(g["attn_out"]).max()))
+    np.testing.assert_allclose(np.array([float(r["pmconv6"].double().sum()), float(r["pmconv6"].double().abs().sum())]),
+                               g["pmconv6_sum"][:2], rtol=1e-4)
+    out, sim = eng_w.attention(r["pmconv6"], hard, want_similar=True)
+    assert _md(sim, g["similar"]) < 5e-4          # 49 keys, saturated softmax on depth-20 activations: 1e-3 is the path's bound
+    assert _md(out, g["attn_out"]) < 1e-4 * max(1.0, float(np.abs(g["attn_out"]).max()))
+    # the oracle's taps agree with the same vectors (CPU: tests/test_oracle_golden.py) -- and with the HIP ones
+    taps = {}
+    WG = synth.make_state_dict("G", 0)
+    with torch.no_grad():
+        O.netG_forward(WG, img, img, g["hard_mask"], g["hard_mask"], sk, taps=taps)
+    assert _md(r["pmconv6"], taps["pmconv6"]) < 1e-4 * max(1.0, float(taps["pmconv6"].abs().max()))
+
+
+@pytest.mark.parametrize("name,H", [("e2e_512.npz", 512), ("e2e_256_crops.npz", 256)], ids=["512", "256"])
+def test_similar_digest_golden(eng_w, golden_dir, name, H):
+    """the HIP attention at L = 3969 keys (512x512; 961 at 256x256) had only ever met the oracle.  Here its
+    `similar` -- se_attention on the pmconv6 output the HIP netG itself produced for the reference's hard mask -- meets the
+    REFERENCE's per-query digests (largest probability, its key index where the winner is clear, position-weighted checksum;
+    tests/golden/make_golden.py similar_digest, /root/reference/models/networks/splitcam.py:57-108)."""
+    from digest_util import check_similar
+    g = _load(golden_dir, name)
+    img, sk = synth.make_inputs(1, H, H, seed=1234)
+    hard_np = np.unpackbits(g["hard_mask_bits"])[: H * H].reshape(1, 1, H, H).astype(np.float32)
+    hard, ci, cs = _cuda(hard_np), _cuda(img), _cuda(sk)
+    r = eng_w.netG_taps(ci, ci, hard, hard, cs, FLAGS)
+    _, sim = eng_w.attention(r["pmconv6"], hard, want_similar=True)
+    assert tuple(sim.shape[1:]) == ((H // 8 - 1) ** 2, H // 8 - 1, H // 8 - 1)
+    check_similar(sim, g, tol=1e-3)
+    # and the production (fused) attention's output against the three-pass one that produced `similar`
+    out3 = eng_w.attention(r["pmconv6"], hard)
+    assert _md(r["attn_out"], out3) < 1e-4 * max(1.0, float(out3.abs().max()))
+
+
+@pytest.mark.parametrize("mode", [("default", dict(low_latency=False)), ("lowlat", dict(low_latency=True))], ids=["default", "lowlat"])
+def test_conservative_flag_selects_the_f2x2_form_in_netM(eng_w, golden_dir, mode, seopt):
+    """SE_FLAG_CONSERVATIVE (include/sketchedit_hip.h): netM's 96 -> 192 layers on F(2x2,3x3), netG unchanged -- bit for bit
+    what the process-wide switch SE_WINOGRAD_F43=2 gives, now chosen per call through the ABI; against the reference's
+    vectors like every other mode."""
+    g = _load(golden_dir, "e2e_256_crops.npz")
+    img, sk = synth.make_inputs(1, 256, 256, seed=1234)
+    ci, cs = _cuda(img), _cuda(sk)
+    base = eng_w.inference(ci, cs, FLAGS, visualize=True, **mode[1])
+    eng_w.set_conservative(True)
+    try:
+        cons = eng_w.inference(ci, cs, FLAGS, visualize=True, **mode[1])
+        m_cons, _ = eng_w.netM(ci, cs, want_image=False)
+    finally:
+        eng_w.set_conservative(False)
+    seopt.set("SE_WINOGRAD_F43", 2)
+    ref2 = eng_w.inference(ci, cs, FLAGS, visualize=True, **mode[1])
+    for k in ("mask", "composed", "coarse", "fine"):
+        assert torch.equal(cons[k], ref2[k]), k
+    _digest_or_mask_only(cons, g, 256, 256)
+    if not mode[1]["low_latency"]:                       # (low-latency mode runs every layer in its direct form: nothing to select)
+        assert not torch.equal(cons["mask"], base["mask"])
+        assert torch.equal(m_cons, cons["mask"])
+    assert _md(cons["mask"], base["mask"]) < 1e-4
+
+
 def test_netM_64_golden(eng_w, golden_dir):
     g = _load(golden_dir, "e2e_64.npz")
     img, sk = synth.make_inputs(2, 64, 64, seed=1234)

@@ -267,6 +267,38 @@ def test_op_attention_all_invalid(golden_dir):
     assert abs(float(P[0, 0, 0, 0]) - 1.0 / P.shape[1]) < 1e-7
 
 
+def att_th_inputs(golden_dir):
+    """the key-validity boundary case of tests/golden/make_golden.py --round6: x from the seed, the mask from the fixture"""
+    g = _load(golden_dir, "ops_r6.npz")
+    x = torch.from_numpy(0.004 * synth.uniform(11, "att_th.x", (2, 96, 12, 16), -1, 1))
+    full = torch.from_numpy(np.unpackbits(g["op.att_th.mask_bits"])[: 2 * 48 * 64].reshape(2, 1, 48, 64).astype(np.float32))
+    return g, x, full
+
+
+def test_op_attention_threshold_boundary(golden_dir):
+    """SURVEY.md 8c / VERDICT r5: key patches with exactly 24, 25, 26 and 27 non-hole pixels of the 256 in their window --
+    25/256 = 0.0977 is NOT > th = 0.1, 26/256 = 0.1016 is (/root/reference/models/networks/splitcam.py:49-53,90).  Scores are
+    soft (P < 0.3), so a key on the wrong side of the threshold moves `similar` by 0.26 (fixture: sensitivity) against a
+    tolerance of 2e-6.  The oracle's validity must agree with the exact integer count."""
+    g, x, full = att_th_inputs(golden_dir)
+    cnt = g["op.att_th.counts"]
+    for b in range(2):
+        assert {24, 25, 26, 27} <= set(cnt[b].ravel().tolist())
+    assert g["op.att_th.sensitivity"].min() > 0.1
+    ms = torch.nn.functional.avg_pool2d(full, 4, 4)
+    valid = torch.nn.functional.unfold(1 - ms, 4, stride=2).view(2, 4, 4, -1).mean(2).mean(1)      # as attention_scores
+    assert np.array_equal((valid > 0.1).numpy().reshape(cnt.shape), cnt >= 26)
+    assert np.array_equal(np.round(valid.numpy().reshape(cnt.shape) * 256).astype(np.int64), cnt)
+    out, P = O.contextual_attention(x, full)
+    assert float(P.max()) < 0.5
+    assert _maxdiff(P, g["op.att_th.similar"]) < TOL
+    assert _maxdiff(out, g["op.att_th.out"]) < 1e-6
+    from oracle import ref_ops
+    out_c, sim_c = ref_ops.attention(x.numpy(), full.numpy())
+    assert _maxdiff(sim_c, g["op.att_th.similar"]) < TOL
+    assert _maxdiff(out_c, g["op.att_th.out"]) < 1e-6
+
+
 # ---- the torch-free C restatement (oracle/ref_ops.c) against the same reference-generated vectors ----
 @pytest.mark.parametrize("case", OPS, ids=[c[0] for c in OPS])
 def test_c_oracle_gated_conv(golden_dir, case):

@@ -14,13 +14,8 @@ import json
 import os
 import sys
 
-LABELS = {"wino_kernel": "wino_n192", "wino24_kernel": "wino_n192", "wino48_kernel": "wino_n96", "winoup_kernel": "wino_up96", "winoup48_kernel": "gconv_n48",
-                 "gconv_kernel<12": "gconv_n192", "gconv_kernel<6": "gconv_n96", "gconv_kernel<3": "gconv_n48", "gconv_kernel<2": "gconv_n24",
-                 "rtile_kernel<3": "gconv_n48", "rtile_kernel<2": "gconv_n24", "rconv16": "gconv_n192", "rconv96": "gconv_n96",
-                 "att2_pair_kernel": "att_score", "att2_pv_kernel": "att_pv", "att2_softmax": "att_softmax", "att2_stats": "att_softmax",
-                 "att2_boxsum": "att_boxsum", "att2_ptilde": "att_boxsum", "att2_prep": "att_prep", "att2_transpose": "att_prep",
-                 "att_score_kernel": "att_score", "att_pv_kernel": "att_pv", "small_conv_kernel": "small_conv", "pack_": "pack",
-                 "colreduce": "colreduce"}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sketchedit_amd.kernel_labels import KERNEL_LABELS as LABELS  # noqa: E402
 
 
 def load(d):
