@@ -129,6 +129,20 @@ int se_inference(se_ctx* ctx, void* stream, const float* image, const float* ske
 int se_inference_u8(se_ctx* ctx, void* stream, const float* image, const float* sketch, unsigned char* rgb_out,
                     unsigned char* mask_u8_out, void* workspace, size_t workspace_bytes, int B, int H, int W, int flags);
 
+/* The INPUT side of test.py's loop on the device (data/testimage_dataset.py:89-111 = ToTensor + Normalize(0.5, 0.5) and
+ * `sketch > 0`): image_u8 (B,H,W,3) uint8 RGB as the PNG decoder delivers it -> image_out (B,3,H,W) fp32 = (v/255 - 0.5)/0.5;
+ * sketch_u8 (B,H,W) uint8 ('L') -> sketch_out (B,1,H,W) fp32 in {0,1}.  The 256 possible image values are tabulated on the
+ * host in IEEE fp32 in that operation order and looked up on the device: bit-identical to the tensors the dataset builds on
+ * the CPU.  Either pair may be NULL.  A 4x smaller host-to-device copy for the caller. */
+int se_dequantize_u8(se_ctx* ctx, void* stream, const unsigned char* image_u8, const unsigned char* sketch_u8, float* image_out,
+                     float* sketch_out, int B, int H, int W);
+
+/* se_inference_u8 fed with the uint8 arrays above: uint8 in, uint8 out -- the whole body of test.py:20-37 between the PNG
+ * decoder and the PNG encoder as one call; the fp32 inputs live in the workspace (se_workspace_bytes includes them). */
+int se_inference_u8io(se_ctx* ctx, void* stream, const unsigned char* image_u8, const unsigned char* sketch_u8,
+                      unsigned char* rgb_out, unsigned char* mask_u8_out, void* workspace, size_t workspace_bytes, int B, int H,
+                      int W, int flags);
+
 /* Output quantisation of test.py:25-27 on the device: rgb_out (B,H,W,3) uint8 = trunc((composed + 1) / 2 * 255)
  * in the HWC order test.py:35 transposes to, mask_u8_out (B,H,W) uint8 = trunc(mask * 255); same fp32 operation
  * order as the reference's tensor expressions, no clamp (as test.py; demo.py:62 clamps -- a [-1,1] input cannot

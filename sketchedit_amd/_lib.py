@@ -28,7 +28,7 @@ LOW_LATENCY_MAX_PIXELS = 4 * 256 * 256
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
            "se_workspace_bytes", "se_netM_forward", "se_netM_forward_ex", "se_netG_forward", "se_netG_forward_taps", "se_inference", "se_inference_u8", "se_gated_conv2d",
-           "se_gated_conv2d_ex", "se_attention", "se_attention_ex", "se_quantize_u8", "se_profile_enable",
+           "se_gated_conv2d_ex", "se_attention", "se_attention_ex", "se_quantize_u8", "se_dequantize_u8", "se_inference_u8io", "se_profile_enable",
            "se_profile_report", "se_debug_set_option", "se_debug_get_option", "se_debug_reset_options"]
 
 
@@ -138,6 +138,10 @@ def load_library():
         lib.se_attention_ex.restype = ci
         lib.se_quantize_u8.argtypes = [vp, vp, c_f, c_f, vp, vp, ci, ci, ci]
         lib.se_quantize_u8.restype = ci
+        lib.se_dequantize_u8.argtypes = [vp, vp, vp, vp, c_f, c_f, ci, ci, ci]
+        lib.se_dequantize_u8.restype = ci
+        lib.se_inference_u8io.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, ci, ci]
+        lib.se_inference_u8io.restype = ci
         lib.se_profile_enable.argtypes = [vp, ci]
         lib.se_profile_enable.restype = ci
         lib.se_profile_report.argtypes = [vp, ctypes.c_char_p, sz]
@@ -212,6 +216,13 @@ def _check_dev(*ts):
             continue
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise SketchEditHipError("expected contiguous float32 CUDA(HIP) tensors")
+
+
+def _check_dev_u8(*ts):
+    import torch
+    for t in ts:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+            raise SketchEditHipError("expected contiguous uint8 CUDA(HIP) tensors")
 
 
 class Engine:
@@ -434,6 +445,35 @@ class Engine:
         if self.lib.se_inference_u8(self.h, self._stream(), _ptr(image), _ptr(sketch), _ptr(rgb), _ptr(m8), _ptr(ws),
                                     ws.numel(), B, H, W, flags):
             self._err("se_inference_u8")
+        return rgb, m8
+
+    def dequantize_u8(self, image_u8, sketch_u8):
+        """data/testimage_dataset.py:89-111 on the device: (B,H,W,3) uint8 RGB, (B,H,W) uint8 'L' -> image (B,3,H,W) fp32 in
+        [-1,1] = (v/255 - 0.5)/0.5, sketch (B,1,H,W) fp32 in {0,1} = (v > 0); bit-identical to the CPU dataset's tensors."""
+        import torch
+        _check_dev_u8(image_u8, sketch_u8)
+        B, H, W, _ = image_u8.shape
+        image = torch.empty((B, 3, H, W), dtype=torch.float32, device=image_u8.device)
+        sketch = torch.empty((B, 1, H, W), dtype=torch.float32, device=image_u8.device)
+        if self.lib.se_dequantize_u8(self.h, self._stream(), _ptr(image_u8), _ptr(sketch_u8), _ptr(image), _ptr(sketch), B, H, W):
+            self._err("se_dequantize_u8")
+        return image, sketch
+
+    def inference_u8io(self, image_u8, sketch_u8, flags, low_latency=None, out=None):
+        """uint8 in, uint8 out: test.py:20-37 between the PNG decoder and the PNG encoder as ONE library call
+        (se_inference_u8io).  image_u8 (B,H,W,3), sketch_u8 (B,H,W) -> (rgb (B,H,W,3), mask (B,H,W)), all uint8 on the device.
+        `out` = (rgb, mask) preallocated."""
+        import torch
+        _check_dev_u8(image_u8, sketch_u8)
+        B, H, W, _ = image_u8.shape
+        assert tuple(sketch_u8.shape) == (B, H, W)
+        ws = self.workspace(B, H, W)
+        rgb, m8 = out if out is not None else (torch.empty((B, H, W, 3), dtype=torch.uint8, device=image_u8.device),
+                                               torch.empty((B, H, W), dtype=torch.uint8, device=image_u8.device))
+        flags = (flags & 31) | self.exec_flags(B, H, W, low_latency, False)
+        if self.lib.se_inference_u8io(self.h, self._stream(), _ptr(image_u8), _ptr(sketch_u8), _ptr(rgb), _ptr(m8), _ptr(ws),
+                                      ws.numel(), B, H, W, flags):
+            self._err("se_inference_u8io")
         return rgb, m8
 
     def inference_packed(self, image, sketch, flags, out, low_latency=None):

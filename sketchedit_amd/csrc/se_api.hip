@@ -146,6 +146,7 @@ struct se_ctx {
   std::map<std::string, Layer> G, M;
   Layer wconv1_j4;          // G.wconv1 packed for a 4-channel input: with --joint_train_inp its guide channel is zero
   float* zeros = nullptr;   // zero page for out-of-bounds granules
+  float* lut8 = nullptr;    // 256 floats: (v/255 - 0.5)/0.5, the dataset's normalisation of a uint8 value (se_dequantize_u8)
   Arena arena;              // workspace arena of the main branch
   Arena arena2;             // low-latency mode: arena of the concurrent side branch (disjoint region of the workspace)
   hipStream_t st = nullptr; // stream the next launch goes to
@@ -1828,6 +1829,22 @@ int se_create(int device_id, se_ctx** out) {
     se_destroy(c);
     return fail(nullptr, "stream / event creation failed");
   }
+  {
+    // data/testimage_dataset.py:89-111 of the reference (ToTensor: /255, Normalize: -0.5, /0.5), one IEEE fp32 operation at a
+    // time on the host (volatile: no reassociation, no reciprocal): the table the device looks up
+    float lut[256];
+    for (int v = 0; v < 256; ++v) {
+      volatile float t = (float)v;
+      t = t / 255.0f;
+      t = t - 0.5f;
+      t = t / 0.5f;
+      lut[v] = t;
+    }
+    if (hipMalloc(&c->lut8, sizeof lut) != hipSuccess || hipMemcpy(c->lut8, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
+      se_destroy(c);
+      return fail(nullptr, "device init failed (dequantisation table)");
+    }
+  }
   for (int i = 0; i < NG; ++i) c->G[G_LAYERS[i].name].def = G_LAYERS[i];
   for (int i = 0; i < NM; ++i) c->M[M_LAYERS[i].name].def = M_LAYERS[i];
   // (the 4-channel form of wconv1 is planned by the dry runs of se_workspace_bytes before any weight exists: a zero stride in
@@ -1868,6 +1885,7 @@ void se_destroy(se_ctx* c) {
   if (c->wconv1_j4.d_wd) (void)hipFree(c->wconv1_j4.d_wd);
   if (c->wconv1_j4.d_wdw) (void)hipFree(c->wconv1_j4.d_wdw);
   if (c->zeros) (void)hipFree(c->zeros);
+  if (c->lut8) (void)hipFree(c->lut8);
   for (auto& e : c->prof.pool) (void)hipEventDestroy(e);
   drop_graphs(c);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1950,7 +1968,8 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
               if (pk.main + pk.side > peak) peak = pk.main + pk.side;
             }
         }
-  return peak + 2 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);   // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes
+  // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes + the fp32 image / sketch of se_inference_u8io (4 planes)
+  return peak + 6 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);
 }
 
 int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float* sketch, float* mask_out,
@@ -2100,6 +2119,37 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
 // The forward with the output quantisation of test.py:25-27 fused into its last kernel: the composite and the soft mask
 // leave the device as uint8 only (a quarter of the fp32 bytes, no separate pass); the soft mask needed between netM and
 // the final composite lives in the workspace.
+namespace {
+// `tail_planes` fp32 (B,H,W) planes at the end of the workspace are the caller's; the soft and hard masks sit in front of them
+int inference_u8_locked(se_ctx* c, void* stream, const float* image, const float* sketch, unsigned char* rgb_out,
+                        unsigned char* mask_u8_out, void* ws, size_t ws_bytes, int B, int H, int W, int flags, int tail_planes) {
+  flags &= ~(SE_FLAG_GRAPH | SE_FLAG_PACKED_OUT);
+  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
+  const size_t tail = (2 + (size_t)tail_planes) * plane;
+  if (ws_bytes < tail) return fail(c, "workspace too small: %zu bytes", ws_bytes);
+  float* hard_all = (float*)((char*)ws + ws_bytes - tail + plane);
+  float* soft_all = (float*)((char*)ws + ws_bytes - tail);
+  const size_t HW = (size_t)H * W;
+  const int nb = pass_size(c, B, H, W, flags);       // passes over image ranges beyond the kernels' 32-bit byte offsets
+  if (!nb) return 1;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    const int bb = std::min(nb, B - b0);
+    const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, false);
+    if (carve(c, pk, ws, ws_bytes, tail)) return 1;
+    const float *img = image + b0 * 3 * HW, *sk = sketch + b0 * HW;
+    float *hard = hard_all + b0 * HW, *soft = soft_all + b0 * HW;
+    begin_call(c, stream, flags);
+    int rc = plan_netM(c, img, sk, soft, hard, nullptr, bb, H, W);
+    if (rc) return rc;
+    if (carve(c, pk, ws, ws_bytes, tail)) return 1;
+    c->rgb8 = rgb_out + b0 * 3 * HW; c->m8 = mask_u8_out ? mask_u8_out + b0 * HW : nullptr;
+    rc = plan_netG(c, img, img, hard, hard, sk, nullptr, nullptr, soft, nullptr, bb, H, W, flags);
+    if (rc) return rc;
+  }
+  return 0;
+}
+}  // namespace
+
 int se_inference_u8(se_ctx* c, void* stream, const float* image, const float* sketch, unsigned char* rgb_out,
                     unsigned char* mask_u8_out, void* ws, size_t ws_bytes, int B, int H, int W, int flags) {
   if (!c) return 1;
@@ -2107,28 +2157,38 @@ int se_inference_u8(se_ctx* c, void* stream, const float* image, const float* sk
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !rgb_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
-  flags &= ~(SE_FLAG_GRAPH | SE_FLAG_PACKED_OUT);
-  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
-  float* hard_all = (float*)((char*)ws + ws_bytes - plane);
-  float* soft_all = (float*)((char*)ws + ws_bytes - 2 * plane);
-  const size_t HW = (size_t)H * W;
-  const int nb = pass_size(c, B, H, W, flags);       // passes over image ranges beyond the kernels' 32-bit byte offsets
-  if (!nb) return 1;
-  for (int b0 = 0; b0 < B; b0 += nb) {
-    const int bb = std::min(nb, B - b0);
-    const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, false);
-    if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
-    const float *img = image + b0 * 3 * HW, *sk = sketch + b0 * HW;
-    float *hard = hard_all + b0 * HW, *soft = soft_all + b0 * HW;
-    begin_call(c, stream, flags);
-    int rc = plan_netM(c, img, sk, soft, hard, nullptr, bb, H, W);
-    if (rc) return rc;
-    if (carve(c, pk, ws, ws_bytes, 2 * plane)) return 1;
-    c->rgb8 = rgb_out + b0 * 3 * HW; c->m8 = mask_u8_out ? mask_u8_out + b0 * HW : nullptr;
-    rc = plan_netG(c, img, img, hard, hard, sk, nullptr, nullptr, soft, nullptr, bb, H, W, flags);
-    if (rc) return rc;
-  }
+  return inference_u8_locked(c, stream, image, sketch, rgb_out, mask_u8_out, ws, ws_bytes, B, H, W, flags, 0);
+}
+
+// data/testimage_dataset.py:89-111 on the device (table lookup; see se_create)
+int se_dequantize_u8(se_ctx* c, void* stream, const unsigned char* image_u8, const unsigned char* sketch_u8, float* image_out,
+                     float* sketch_out, int B, int H, int W) {
+  if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (check_dims(c, B, H, W)) return 1;
+  if ((image_out && !image_u8) || (sketch_out && !sketch_u8)) return fail(c, "null pointer argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  set_profiler(&c->prof);
+  HIPCHK(c, launch_dequantize_u8(image_u8, sketch_u8, c->lut8, image_out, sketch_out, B, H, W, (hipStream_t)stream));
   return 0;
+}
+
+// uint8 in, uint8 out: the fp32 image (3 planes) and sketch (1 plane) live at the very end of the workspace
+int se_inference_u8io(se_ctx* c, void* stream, const unsigned char* image_u8, const unsigned char* sketch_u8,
+                      unsigned char* rgb_out, unsigned char* mask_u8_out, void* ws, size_t ws_bytes, int B, int H, int W,
+                      int flags) {
+  if (!c) return 1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (check_dims(c, B, H, W)) return 1;
+  if (!image_u8 || !sketch_u8 || !rgb_out || !ws) return fail(c, "null pointer argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
+  if (ws_bytes < 6 * plane) return fail(c, "workspace too small: %zu bytes", ws_bytes);
+  float* image = (float*)((char*)ws + ws_bytes - 4 * plane);      // (B,3,H,W) contiguous: 3 B H W floats <= 3 planes
+  float* sketch = (float*)((char*)ws + ws_bytes - plane);
+  set_profiler(&c->prof);
+  HIPCHK(c, launch_dequantize_u8(image_u8, sketch_u8, c->lut8, image, sketch, B, H, W, (hipStream_t)stream));
+  return inference_u8_locked(c, stream, image, sketch, rgb_out, mask_u8_out, ws, ws_bytes, B, H, W, flags, 4);
 }
 
 // test.py:25-27 on the device

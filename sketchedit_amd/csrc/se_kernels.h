@@ -280,6 +280,8 @@ hipError_t launch_pack_g(const float* x, const float* x2, const float* mask, con
                          float* coarse8, float* style8, int B, int H, int W, int no_mask_cc, int joint,
                          hipStream_t st);
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int B, int C, int Cpad, int H, int W, hipStream_t st);
+hipError_t launch_dequantize_u8(const unsigned char* rgb, const unsigned char* sk8, const float* lut, float* image, float* sketch,
+                                int B, int H, int W, hipStream_t st);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st);
 // test.py:25-27 output quantisation: composed NCHW (B,3,H,W) -> rgb HWC uint8, mask (B,1,H,W) -> uint8; W % 4 == 0
 hipError_t launch_quantize_u8(const float* composed, const float* mask, unsigned char* rgb, unsigned char* m8, int B, int H,

@@ -528,6 +528,43 @@ hipError_t launch_quantize_u8(const float* composed, const float* mask, unsigned
   return hipGetLastError();
 }
 
+// ---- input dequantisation (data/testimage_dataset.py:89-111 of the reference: ToTensor + Normalize(0.5, 0.5), sketch > 0):
+// 4 consecutive pixels per thread -- 12 + 4 input bytes, four float4 stores.  The 256 possible image values come from a table
+// the HOST computed with IEEE fp32 division in the dataset's operation order (se_api.hip dequant_table): bit-identical to the
+// float tensors the CPU dataset builds, whatever the device's division does.
+__global__ void dequant_u8_kernel(const unsigned char* __restrict__ rgb, const unsigned char* __restrict__ sk8,
+                                  const float* __restrict__ lut, float* __restrict__ image, float* __restrict__ sketch, int B, int HW) {
+  __shared__ float T[256];
+  T[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;      // group of 4 pixels
+  if (q >= (long)B * HW / 4) return;
+  const long pix = q * 4;
+  const int b = (int)(pix / HW);
+  const long in = pix - (long)b * HW;
+  if (image) {
+    const unsigned* src = (const unsigned*)(rgb + pix * 3);
+    const unsigned w0 = src[0], w1 = src[1], w2 = src[2];
+    unsigned char v[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (w0 >> (8 * i)) & 255u; v[4 + i] = (w1 >> (8 * i)) & 255u; v[8 + i] = (w2 >> (8 * i)) & 255u; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      *(float4*)(image + ((long)b * 3 + c) * HW + in) = make_float4(T[v[c]], T[v[3 + c]], T[v[6 + c]], T[v[9 + c]]);
+  }
+  if (sketch) {
+    const unsigned w = *(const unsigned*)(sk8 + pix);
+    *(float4*)(sketch + pix) = make_float4((w & 0xffu) ? 1.f : 0.f, (w & 0xff00u) ? 1.f : 0.f, (w & 0xff0000u) ? 1.f : 0.f, (w & 0xff000000u) ? 1.f : 0.f);
+  }
+}
+hipError_t launch_dequantize_u8(const unsigned char* rgb, const unsigned char* sk8, const float* lut, float* image, float* sketch,
+                                int B, int H, int W, hipStream_t st) {
+  const long nq = (long)B * H * W / 4;
+  ProfScope ps_(st, PL_LAYOUT);
+  hipLaunchKernelGGL(dequant_u8_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, rgb, sk8, lut, image, sketch, B, H * W);
+  return hipGetLastError();
+}
+
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int Cstride, int H, int W, hipStream_t st) {
   const long n = (long)B * C * H * W;
   ProfScope ps_(st, PL_LAYOUT);

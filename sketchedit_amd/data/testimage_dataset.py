@@ -22,6 +22,10 @@ class TestImageDataset(BaseDataset):
 
     def initialize(self, opt):
         self.opt = opt
+        # u8 mode (no reference counterpart; set by test.py's pipelined loop): items carry the decoder's uint8 arrays --
+        # 'image_u8' (H,W,3), 'mask_u8' (H,W) -- instead of the float tensors; the normalisation below then runs on the device
+        # (se_inference_u8io), bit-identically.  A quarter of the bytes through the worker pipes and the PCIe link.
+        self.u8 = bool(getattr(opt, "u8_io", False))
         os.makedirs(opt.output_dir, exist_ok=True)
         if opt.output_mask_dir is not None:
             os.makedirs(opt.output_mask_dir, exist_ok=True)
@@ -47,6 +51,10 @@ class TestImageDataset(BaseDataset):
     def __getitem__(self, index):
         image = Image.open(self.image_paths[index]).convert("RGB")
         w, h = image.size
+        if self.u8:
+            sketch = Image.open(self.mask_paths[index]).convert("L").resize((w, h))
+            return {"image_u8": torch.from_numpy(np.array(image, dtype=np.uint8)),
+                    "mask_u8": torch.from_numpy(np.array(sketch, dtype=np.uint8)), "path": self.output_paths[index]}
         arr = np.asarray(image, dtype=np.float32).transpose(2, 0, 1) / 255.0
         image_tensor = torch.from_numpy((arr - 0.5) / 0.5)
         sketch = Image.open(self.mask_paths[index]).convert("L").resize((w, h))

@@ -90,9 +90,18 @@ class EditLine2Model(torch.nn.Module):
         """mode='inference' followed by test.py:25-27 -- `((generated + 1) / 2 * 255).astype(uint8)` in HWC order and
         `(mask * 255).astype(uint8)` -- as ONE library call: the quantisation is fused into the forward's last kernel, so
         only uint8 leaves the device.  -> (rgb (B,H,W,3) uint8, mask (B,H,W) uint8), both on the device."""
-        inputs, _, line, _, _ = self.preprocess_input(data)
         if self.training:
             raise NotImplementedError("call model.eval() first: only the eval branch of generate_fake exists here")
+        if "image_u8" in data:
+            # uint8 all the way (the dataset's u8 mode, data/testimage_dataset.py): the normalisation of
+            # /root/reference/data/testimage_dataset.py:89-111 happens on the device too (table lookup, bit-identical)
+            dev = torch.device("cuda", self.opt.gpu_ids[0])
+            iu8, su8 = data["image_u8"].to(dev, non_blocking=True), data["mask_u8"].to(dev, non_blocking=True)
+            B, H, W, _ = iu8.shape
+            with torch.no_grad():
+                return self.engine().inference_u8io(iu8.contiguous(), su8.contiguous(), _lib.flags_from_opt(self.opt),
+                                                    low_latency=self._mode_for(B, H, W, low_latency))
+        inputs, _, line, _, _ = self.preprocess_input(data)
         eng = self.engine()
         with torch.no_grad():
             return eng.inference_u8(inputs.float().contiguous(), line.float().contiguous(), _lib.flags_from_opt(self.opt),
