@@ -241,6 +241,63 @@ def test_test_py_script_end_to_end(tmp_path, model):
         assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
+def test_dequantize_u8_is_the_datasets_normalisation_bit_for_bit(model):
+    """se_dequantize_u8 (table built on the host, looked up on the device) against the float tensors the dataset builds on the
+    CPU (sketchedit_amd/data/testimage_dataset.py = /root/reference/data/testimage_dataset.py:89-111: ToTensor + Normalize(0.5,
+    0.5), sketch > 0) for EVERY uint8 value, and se_inference_u8io against se_inference_u8 on those tensors: identical bytes."""
+    eng = model.engine()
+    rng = np.random.RandomState(3)
+    iu8 = rng.randint(0, 256, (2, 64, 64, 3)).astype(np.uint8)
+    iu8[0].reshape(-1)[:256] = np.arange(256, dtype=np.uint8)                   # every value occurs
+    su8 = (rng.rand(2, 64, 64) < 0.02).astype(np.uint8) * rng.randint(1, 256, (2, 64, 64)).astype(np.uint8)
+    img, sk = eng.dequantize_u8(torch.from_numpy(iu8).cuda(), torch.from_numpy(su8).cuda())
+    arr = iu8.astype(np.float32).transpose(0, 3, 1, 2) / 255.0
+    want = np.ascontiguousarray((arr - 0.5) / 0.5)
+    assert want.dtype == np.float32
+    assert np.array_equal(img.cpu().numpy(), want)
+    assert np.array_equal(sk.cpu().numpy(), (su8.astype(np.float32)[:, None] / 255.0 > 0).astype(np.float32))
+    for ll in (False, True):
+        a = eng.inference_u8io(torch.from_numpy(iu8).cuda(), torch.from_numpy(su8).cuda(), 1 | 2 | 16, low_latency=ll)
+        b = eng.inference_u8(torch.from_numpy(want).cuda(), sk, 1 | 2 | 16, low_latency=ll)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_pipelined_test_py_writes_the_serial_loops_files(tmp_path):
+    """test.py's pipeline (worker processes -> pinned uint8 -> three streams -> encoder threads, sketchedit_amd/pipeline.py)
+    against its --serial_io loop (the reference's structure, /root/reference/test.py:20-37): byte-identical PNG files, in
+    every directory, for a list that ends in a ragged batch; --how_many stops both at the same file."""
+    from PIL import Image
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    rng = np.random.RandomState(1)
+    names = ["g%d.png" % i for i in range(7)]
+    for n in names:
+        Image.fromarray(rng.randint(0, 255, (64, 96, 3), dtype=np.uint8)).save(tmp_path / "images" / n)
+        Image.fromarray(((rng.rand(64, 96) < 0.01) * 255).astype(np.uint8)).save(tmp_path / "edges" / n)
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    base = ("--batchSize 3 --name celeb --joint_train_inp --dataset_mode testimage --image_dirs {d}/images "
+            "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
+            "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --synthetic_weights ").format(d=tmp_path)
+    _run_test_py((base + "--nThreads 0 --serial_io --output_dir {d}/s --output_mask_dir {d}/sm".format(d=tmp_path)).split())
+    _run_test_py((base + "--nThreads 2 --encode_threads 3 --pipeline_depth 2 --output_dir {d}/p --output_mask_dir {d}/pm".format(d=tmp_path)).split())
+    _run_test_py((base + "--nThreads 0 --pipeline_depth 1 --output_dir {d}/q".format(d=tmp_path)).split())
+    # encoder PROCESSES fed through the shared page-locked ring (hipHostRegister on a /dev/shm file), masks too
+    _run_test_py((base + "--nThreads 2 --encode_procs 2 --output_dir {d}/r --output_mask_dir {d}/rm".format(d=tmp_path)).split())
+    # the reference's cv2.imwrite settings written directly: other bytes, the same pixels
+    _run_test_py((base + "--nThreads 1 --encode_procs 2 --png_writer fast --output_dir {d}/f --output_mask_dir {d}/fm".format(d=tmp_path)).split())
+    for n in names:
+        ref = (tmp_path / "s" / n).read_bytes()
+        assert (tmp_path / "p" / n).read_bytes() == ref and (tmp_path / "q" / n).read_bytes() == ref, n
+        assert (tmp_path / "r" / n).read_bytes() == ref, n
+        assert (tmp_path / "pm" / n).read_bytes() == (tmp_path / "sm" / n).read_bytes(), n
+        assert (tmp_path / "rm" / n).read_bytes() == (tmp_path / "sm" / n).read_bytes(), n
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "f" / n)), np.asarray(Image.open(tmp_path / "s" / n))), n
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "fm" / n)), np.asarray(Image.open(tmp_path / "sm" / n))), n
+    _run_test_py((base + "--nThreads 1 --how_many 4 --output_dir {d}/h".format(d=tmp_path)).split())
+    _run_test_py((base + "--nThreads 0 --serial_io --how_many 4 --output_dir {d}/hs".format(d=tmp_path)).split())
+    assert sorted(os.listdir(tmp_path / "h")) == sorted(os.listdir(tmp_path / "hs")) == names[:6]       # test.py:21-22: whole batches
+
+
 def test_celeb_sample_through_test_py_matches_the_reference(tmp_path, golden_dir, model):
     """BASELINE config 1: test_celeb.sh's command line (batch 1) on the reference's bundled face + sketch -- written
     back to PNG files from the fixture -- gives the PNGs the reference produces (fixture: tests/golden/make_golden.py)."""

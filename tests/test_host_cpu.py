@@ -482,18 +482,30 @@ def test_developer_switches_are_a_table_read_once():
     path), changed afterwards only through se_debug_set_option.  No device needed: the table lives on the host."""
     import subprocess
     import sys
-    assert _lib.get_option("SE_WINOGRAD_F43") == 1 and _lib.get_option("WINOGRAD_F43") == 1      # with or without the prefix
-    assert _lib.get_option("SE_ATT_FUSED") == -1 and _lib.get_option("SE_RTILE_WX") == 2
-    _lib.set_option("SE_WINOGRAD_F43", 2)
-    _lib.set_option("SE_TEST_OFFSET_LIMIT", 12345)
-    assert _lib.get_option("SE_WINOGRAD_F43") == 2 and _lib.get_option("SE_TEST_OFFSET_LIMIT") == 12345
-    os.environ["SE_WINOGRAD_F43"] = "0"                  # the environment is not consulted again
-    try:
+    # built-in defaults: asserted in a child whose environment carries no SE_* variable (ADVICE r5: in-process asserts failed
+    # whenever an A/B variable was exported)
+    scrub = {k: v for k, v in os.environ.items() if not k.startswith("SE_")}
+    code0 = ("from sketchedit_amd import _lib; print(_lib.get_option('SE_WINOGRAD_F43'), _lib.get_option('WINOGRAD_F43'), "
+             "_lib.get_option('SE_ATT_FUSED'), _lib.get_option('SE_RTILE_WX'))")
+    out0 = subprocess.run([sys.executable, "-c", code0], cwd=ROOT, env=scrub, capture_output=True, text=True, timeout=300)
+    assert out0.returncode == 0, out0.stderr[-2000:]
+    assert out0.stdout.split() == ["1", "1", "-1", "2"]                        # with or without the prefix
+    base_f43 = _lib.get_option("SE_WINOGRAD_F43")
+    saved_env = os.environ.get("SE_WINOGRAD_F43")
+    try:                                                  # every mutation inside try / finally: nothing leaks into later tests
+        _lib.set_option("SE_WINOGRAD_F43", 2)
+        _lib.set_option("SE_TEST_OFFSET_LIMIT", 12345)
+        assert _lib.get_option("SE_WINOGRAD_F43") == 2 and _lib.get_option("SE_TEST_OFFSET_LIMIT") == 12345
+        os.environ["SE_WINOGRAD_F43"] = "0"              # the environment is not consulted again
         assert _lib.get_option("SE_WINOGRAD_F43") == 2
         _lib.reset_options()
-        assert _lib.get_option("SE_WINOGRAD_F43") == 1 and _lib.get_option("SE_TEST_OFFSET_LIMIT") == 0
+        assert _lib.get_option("SE_WINOGRAD_F43") == base_f43 and _lib.get_option("SE_TEST_OFFSET_LIMIT") == 0
     finally:
-        del os.environ["SE_WINOGRAD_F43"]
+        _lib.reset_options()
+        if saved_env is None:
+            os.environ.pop("SE_WINOGRAD_F43", None)
+        else:
+            os.environ["SE_WINOGRAD_F43"] = saved_env
     with pytest.raises(_lib.SketchEditHipError):
         _lib.set_option("SE_NO_SUCH_SWITCH", 1)
     with pytest.raises(_lib.SketchEditHipError):
@@ -505,3 +517,102 @@ def test_developer_switches_are_a_table_read_once():
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split() == ["2", "0", "0"]
+
+
+def test_dataset_u8_mode_carries_the_decoders_arrays(tmp_path):
+    """u8 mode of the dataset (test.py's pipelined loop): the uint8 arrays the float path normalises -- (v/255 - 0.5)/0.5 and
+    sketch > 0 (/root/reference/data/testimage_dataset.py:89-111) applied to them gives the float path's tensors exactly."""
+    from PIL import Image
+    from sketchedit_amd import data
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 255, (48, 64, 3), dtype=np.uint8)).save(tmp_path / "images" / ("im%d.png" % i))
+        Image.fromarray((rng.rand(24, 32) < 0.05).astype(np.uint8) * 255).save(tmp_path / "edges" / ("im%d.png" % i))
+    (tmp_path / "list.txt").write_text("im0.png\nim1.png\nim2.png\n")
+    o = _opt(tmp_path)
+    o.nThreads, o.batchSize = 0, 2
+    f = next(iter(data.create_dataloader(o)))
+    o.u8_io = True
+    u = next(iter(data.create_dataloader(o)))
+    assert u["image_u8"].dtype == torch.uint8 and tuple(u["image_u8"].shape) == (2, 48, 64, 3) and tuple(u["mask_u8"].shape) == (2, 48, 64)
+    assert "image" not in u and u["path"] == f["path"]
+    want = (u["image_u8"].numpy().astype(np.float32).transpose(0, 3, 1, 2) / 255.0 - 0.5) / 0.5
+    assert np.array_equal(want, f["image"].numpy())
+    assert np.array_equal((u["mask_u8"].numpy() > 0).astype(np.float32)[:, None], f["mask"].numpy())
+
+
+def test_host_codec_capability_and_synthetic_pairs(tmp_path):
+    """the host-only yardstick of bench.py --e2e (decode processes + encoder threads, no GPU) on a few tiny pairs"""
+    import importlib.util
+    from sketchedit_amd.pipeline import host_codec_capability
+    spec = importlib.util.spec_from_file_location("se_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    for i in range(3):
+        bench._write_pair((str(tmp_path), i, 64))
+    ip = [str(tmp_path / "images" / ("u%04d.png" % i)) for i in range(3)]
+    mp_ = [str(tmp_path / "edges" / ("u%04d.png" % i)) for i in range(3)]
+    os.makedirs(tmp_path / "cap")
+    for writer in ("pil", "fast"):
+        cap = host_codec_capability(ip, mp_, 2, 2, seconds=0.5, writer=writer, out_dir=str(tmp_path / "cap"))
+        assert cap["decode_ips"] > 0 and cap["encode_ips"] > 0 and 0 < cap["both_ips"] <= max(cap["both_decode_ips"], cap["both_encode_ips"])
+
+
+def test_png_writers_and_encoder_processes(tmp_path):
+    """The two PNG writers of the I/O path (sketchedit_amd/png_worker.py): `pil` = Image.save's defaults, byte for byte; `fast`
+    = the reference's cv2.imwrite settings (SUB filter, zlib 1, RLE; /root/reference/test.py:37) written directly -- a valid PNG
+    with the same pixels.  And the encoder PROCESS protocol of the pipeline: jobs name a slot of a ring file, results land on
+    disk, a failing job raises in the caller."""
+    import io
+    from PIL import Image
+    from sketchedit_amd.png_worker import png_bytes_fast, save_png
+    from sketchedit_amd.pipeline import _EncoderProcs
+    rng = np.random.RandomState(5)
+    for shape in ((40, 72, 3), (17, 5, 3), (64, 64), (1, 1, 3)):
+        a = rng.randint(0, 256, shape).astype(np.uint8)
+        back = np.asarray(Image.open(io.BytesIO(png_bytes_fast(a))))
+        assert back.shape == a.shape and np.array_equal(back, a), shape
+    a = rng.randint(0, 256, (32, 48, 3)).astype(np.uint8)
+    save_png(a, str(tmp_path / "p.png"))
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="PNG")
+    assert (tmp_path / "p.png").read_bytes() == buf.getvalue()
+    # ring of 3 slots x 4 images; two worker processes
+    ring = np.memmap(str(tmp_path / "ring"), dtype=np.uint8, mode="w+", shape=(3, 4, 32, 48, 3))
+    ring[:] = rng.randint(0, 256, ring.shape).astype(np.uint8)
+    mring = np.memmap(str(tmp_path / "mring"), dtype=np.uint8, mode="w+", shape=(3, 4, 32, 48))
+    mring[:] = rng.randint(0, 256, mring.shape).astype(np.uint8)
+    ring.flush(); mring.flush()
+    os.makedirs(tmp_path / "o"); os.makedirs(tmp_path / "m")
+    procs = _EncoderProcs(2)
+    try:
+        job = dict(rgb_ring=str(tmp_path / "ring"), rgb_shape=ring.shape, mask_ring=str(tmp_path / "mring"), mask_shape=mring.shape,
+                   slot=1, out_dir=str(tmp_path / "o"), mask_dir=str(tmp_path / "m"))
+        futs = [procs.submit(dict(job, first=0, paths=["a.png", "b.png"], writer="pil")),
+                procs.submit(dict(job, first=2, paths=["c.png", "d.png"], writer="fast"))]
+        assert all(f.result(timeout=60) > 0 for f in futs)
+        for i, n in enumerate("abcd"):
+            assert np.array_equal(np.asarray(Image.open(tmp_path / "o" / (n + ".png"))), ring[1, i])
+            assert np.array_equal(np.asarray(Image.open(tmp_path / "m" / (n + ".png"))), mring[1, i])
+        buf = io.BytesIO()
+        Image.fromarray(np.asarray(ring[1, 0])).save(buf, format="PNG")
+        assert (tmp_path / "o" / "a.png").read_bytes() == buf.getvalue()
+        bad = procs.submit(dict(job, first=0, paths=["x.png"], out_dir=str(tmp_path / "no_such_dir"), writer="pil"))
+        with pytest.raises(RuntimeError):
+            bad.result(timeout=60)
+    finally:
+        procs.close()
+
+
+def test_effective_cpus_honours_a_cgroup_quota(monkeypatch, tmp_path):
+    from sketchedit_amd import hostinfo
+    n = hostinfo.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 2.0)
+    assert hostinfo.effective_cpus() == min(2, len(os.sched_getaffinity(0)))
+    monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 0.5)
+    assert hostinfo.effective_cpus() == 1
