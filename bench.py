@@ -438,8 +438,8 @@ def e2e_leg(args):
     the process may really use (affinity AND cgroup quota: the GPU boxes grant 16 CPUs' worth of time on a 256-CPU host)."""
     import multiprocessing as mp
     from argparse import Namespace
-    from sketchedit_amd.hostinfo import cgroup_cpu_quota, effective_cpus
-    from sketchedit_amd.pipeline import InferencePipeline, host_codec_capability
+    from sketchedit_amd.hostinfo import cgroup_cpu_quota, cgroup_throttle_stats, effective_cpus
+    from sketchedit_amd.pipeline import InferencePipeline, encoder_rate_on, host_codec_capability
     ncpu = effective_cpus()
     torch.set_num_threads(max(1, min(torch.get_num_threads(), ncpu // 2 or 1)))
     S, B, N, U = args.size, args.batch, args.e2e_images, min(args.e2e_unique, args.e2e_images)
@@ -462,12 +462,15 @@ def e2e_leg(args):
         gen_s = time.perf_counter() - t0
         ip = [os.path.join(d, "images", "u%04d.png" % i) for i in range(U)]
         mp_ = [os.path.join(d, "edges", "u%04d.png" % i) for i in range(U)]
-        # pool sizes: one CPU stays with the main thread (launches, staging copies); the rest is split by the stages' cost per
-        # image (decode ~2.5 ms per pair; encode ~13-18 ms with PIL's defaults, ~2.5 ms with the fast writer)
+        # pool sizes: `reserve` CPUs stay with the main process (launch thread, staging copies, the loader's and the encoders'
+        # helper threads, the HIP runtime's): under a cgroup quota an over-committed pool does not just slow down, it gets EVERY
+        # thread of the cgroup stopped until the period ends -- the launch thread too.  The rest is split by the stages' cost
+        # per image (decode ~1.6 ms per pair; encode ~7 ms with PIL's defaults, ~1.3 ms with the fast writer, EPYC 9575F)
         plans = {}
+        reserve = args.e2e_reserve if args.e2e_reserve >= 0 else max(1, ncpu // 5)
         for writer, dec_share in (("pil", 0.2), ("fast", 0.5)):
-            w = args.e2e_workers or max(1, int(round((ncpu - 1) * dec_share)))
-            e = args.e2e_encoders or max(1, ncpu - 1 - w)
+            w = args.e2e_workers or max(1, int(round((ncpu - reserve) * dec_share)))
+            e = args.e2e_encoders or max(1, ncpu - reserve - w)
             plans[writer] = (w, e, host_codec_capability(ip, mp_, w, e, seconds=args.e2e_cap_seconds, writer=writer, out_dir=os.path.join(d, "cap")))
         # ---- the GPU side starts here
         from sketchedit_amd import data, models
@@ -491,30 +494,45 @@ def e2e_leg(args):
         legs = {}
         for writer, (w, e, cap) in plans.items():
             opt.nThreads = w
+            thr0 = cgroup_throttle_stats()
             loader = data.create_dataloader(opt)
             pipe = InferencePipeline(model, opt.output_dir, None, encode_threads=e, depth=args.e2e_depth, timing=True, verbose=False,
                                      encode_procs=0 if args.e2e_encode_threads else e, max_pending_batches=args.e2e_pending, png_writer=writer)
             st = dict(pipe.run(loader, float("inf"), B))
             pipe.close()
+            thr1 = cgroup_throttle_stats()
             img = st["images"]
+            # the encoders' rate on what the network really wrote (procedural weights paint the hole with texture that
+            # compresses worse than the synthetic inputs the host-only capability leg encodes): the fair yardstick for `encode`
+            from PIL import Image
+            outs = sorted(os.listdir(opt.output_dir))
+            sample = np.array(Image.open(os.path.join(opt.output_dir, outs[len(outs) // 2])).convert("RGB"), dtype=np.uint8)
+            out_bytes = float(np.mean([os.path.getsize(os.path.join(opt.output_dir, f)) for f in outs[:: max(1, len(outs) // 64)]]))
+            os.makedirs(os.path.join(d, "rate"), exist_ok=True)
+            enc_out = encoder_rate_on(sample, os.path.join(d, "rate"), e, writer, seconds=args.e2e_cap_seconds)
             stage = {"decode": cap["decode_ips"], "h2d": img / max(st["h2d_ms"] * 1e-3, 1e-9), "forward": img / max(st["forward_ms"] * 1e-3, 1e-9),
-                     "d2h": img / max(st["d2h_ms"] * 1e-3, 1e-9), "encode": cap["encode_ips"]}
+                     "d2h": img / max(st["d2h_ms"] * 1e-3, 1e-9), "encode": enc_out}
             e2e = img / st["wall_s"]
             legs[writer] = {
                 "e2e_images_per_sec": round(e2e, 1), "images": img, "files_written": len(os.listdir(opt.output_dir)), "wall_s": round(st["wall_s"], 3),
                 "decode_workers": w, "encode_workers": e, "encoders_are": "threads" if args.e2e_encode_threads else "processes",
-                # standalone rate of every stage (images/sec): decode / encode = the host alone at these worker counts (no GPU);
+                # standalone rate of every stage (images/sec): decode = the host alone at this worker count (no GPU), encode = the
+                # encoder processes alone on an image the network produced;
                 # h2d / forward / d2h = images / summed HIP-event time of that stage inside the pipelined run
                 "stage_images_per_sec": {k: round(v, 1) for k, v in stage.items()},
                 "bottleneck": min(stage, key=stage.get),
-                "host_codec": {k: round(v, 1) for k, v in cap.items()},
+                "host_codec": dict({k: round(v, 1) for k, v in cap.items()}, encode_ips_on_network_output=round(enc_out, 1),
+                                   mean_output_png_bytes=round(out_bytes)),
                 # the yardstick: what these CPUs decode + encode in parallel with no GPU in the loop
                 "e2e_over_host_codec": round(e2e / max(cap["both_ips"], 1e-9), 3),
                 # ... and against the slowest stage's standalone rate (the forward when the codec outruns the GPU)
                 "e2e_over_slowest_stage": round(e2e / max(min(stage.values()), 1e-9), 3),
                 "main_thread_s": {k: round(st[k], 3) for k in ("decode_wait_s", "sync_wait_s", "encode_backpressure_s", "encode_drain_s", "issue_stage_s",
                                                                 "issue_h2d_s", "issue_forward_s", "issue_d2h_s", "submit_encode_s")},
-                "encode_cpu_s_summed": round(st["encode_cpu_s"], 2)}
+                "encode_cpu_s_summed": round(st["encode_cpu_s"], 2),
+                # scheduler periods (100 ms) of the run / periods in which the cgroup's CPU quota stopped every thread / time stopped
+                "cgroup_throttling": (None if not (thr0 and thr1) else {"periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1],
+                                                                          "throttled_thread_seconds": round((thr1[2] - thr0[2]) * 1e-6, 3)})}
         main_leg = legs["pil"]
         line = {"metric": "e2e_images_per_sec", "value": main_leg["e2e_images_per_sec"], "unit": "images/sec", "size": S, "batch": B,
                 "what": "test.py's loop, files to files: PNG pair on tmpfs -> decode (worker processes) -> page-locked uint8 ring -> H2D -> "
@@ -581,6 +599,7 @@ def main():
     ap.add_argument("--e2e-workers", type=int, default=0, help="decode worker processes (0: by host size)")
     ap.add_argument("--e2e-encoders", type=int, default=0, help="PNG encoder threads (0: by host size)")
     ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight on the device")
+    ap.add_argument("--e2e-reserve", type=int, default=-1, help="CPUs left to the main process (-1: a fifth of the effective CPUs)")
     ap.add_argument("--e2e-pending", type=int, default=8, help="batches that may wait for their encoders")
     ap.add_argument("--e2e-encode-threads", action="store_true", help="encoder THREADS in the main process instead of processes (GIL-bound near 2000 images/s)")
     ap.add_argument("--e2e-cap-seconds", type=float, default=3.0, help="seconds per host-codec capability leg (decode, encode, both)")

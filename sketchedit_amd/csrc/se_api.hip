@@ -1426,7 +1426,8 @@ struct Plan {
   // side arena; it starts after everything enqueued on the main stream so far (fork event) and join() makes the main
   // stream wait for it.  A buffer shared by both branches must be released only after join().  Outside low-latency mode
   // the calls do nothing: the branch is planned in line, on the main stream and arena.
-  bool forked() const { return c->low_latency && c->st_side; }
+  // (SE_FORK_DEFAULT=1: the two-stream plan in the default mode too -- an A/B switch, measured in round 6: DESIGN.md 7b)
+  bool forked() const { return (c->low_latency || opt(OPT_FORK_DEFAULT) != 0) && c->st_side; }
   int side_begin() {
     if (!forked()) return 0;
     ar = &c->arena2;

@@ -35,3 +35,17 @@ def effective_cpus():
     if q is not None:
         n = min(n, max(1, int(math.floor(q + 1e-9))))
     return max(1, n)
+
+
+def cgroup_throttle_stats():
+    """(nr_periods, nr_throttled, throttled_usec) of this process's cgroup (v2 cpu.stat), or None: how often the CPU quota
+    stopped EVERY thread of the cgroup -- the launch thread included -- until the end of a scheduler period"""
+    try:
+        d = {}
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            for ln in f:
+                k, _, v = ln.partition(" ")
+                d[k] = int(v)
+        return d.get("nr_periods", 0), d.get("nr_throttled", 0), d.get("throttled_usec", 0)
+    except (OSError, ValueError):
+        return None

@@ -384,3 +384,39 @@ def host_codec_capability(image_paths, mask_paths, decode_workers, encode_worker
             out["both_decode_ips"], out["both_encode_ips"] = nd / dt, ne / dt
             out["both_ips"] = min(nd, ne) / dt          # a pipeline moves at its slower stage
     return out
+
+
+def encoder_rate_on(array, out_dir, workers, writer="pil", seconds=3.0):
+    """images/s at which `workers` encoder PROCESSES (the pipeline's own: python -m sketchedit_amd.png_worker) encode + write
+    `array` -- an image the network really produced -- for `seconds`.  Safe after the GPU is in use (nothing is forked)."""
+    ring_path = os.path.join(out_dir, "_rate_ring")
+    shape = (1, 4) + tuple(array.shape)
+    mm = np.memmap(ring_path, dtype=np.uint8, mode="w+", shape=shape)
+    mm[0, :] = array
+    mm.flush()
+    procs = _EncoderProcs(workers)
+    done, t0 = 0, time.perf_counter()
+    try:
+        job = dict(rgb_ring=ring_path, rgb_shape=shape, mask_ring=None, mask_shape=None, slot=0, first=0, out_dir=out_dir, mask_dir=None, writer=writer)
+        futs = deque()
+        k = 0
+        while time.perf_counter() - t0 < seconds:
+            while len(futs) < 3 * workers:
+                futs.append(procs.submit(dict(job, paths=["_rate_%d_%d.png" % (k % (3 * workers), j) for j in range(4)])))
+                k += 1
+            futs.popleft().result()
+            done += 4
+        for f in futs:
+            f.result()
+            done += 4
+        dt = time.perf_counter() - t0
+    finally:
+        procs.close()
+        del mm
+        for f in os.listdir(out_dir):
+            if f.startswith("_rate_"):
+                try:
+                    os.unlink(os.path.join(out_dir, f))
+                except OSError:
+                    pass
+    return done / dt
