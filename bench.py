@@ -62,6 +62,11 @@ LIVE_GFLOP_PER_IMAGE = {256: 90.80, 512: 437.27}
 from sketchedit_amd.kernel_labels import KERNEL_LABELS, label_of  # noqa: E402  (rocprofv3 kernel names -> profiler labels)
 
 
+def _lib_opt(name):
+    from sketchedit_amd import _lib
+    return _lib.get_option(name)
+
+
 def cpu_baseline(budget_s=25.0):
     """Time the oracle on the host cores at the sizes SURVEY.md 8d names: 256x256 batch 1 and 8, 512x512 batch 1."""
     from oracle import sketchedit_oracle as O
@@ -176,8 +181,10 @@ def pmc_traffic(argv_child, timeout_s=240):
         # pass 0: --kernel-trace alone -> average launch duration per label WITHOUT the in-library event pairs (which cost the
         # first launch after a different kernel ~50 us at 256x256 batch 32: the events' own cache maintenance)
         d = os.path.join(tmp, "trace")
+        # SE_FORK_DEFAULT=0 in every child pass: per-kernel durations / bytes are properties of ONE kernel only when nothing else
+        # shares the chip; the timed headline runs the default two-stream plan (config.execution)
         cmd = [exe, "--kernel-trace", "-d", d, "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py")] + argv_child
-        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", SE_FORK_DEFAULT="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
         if p.returncode == 0 and files:
             dur = {}
@@ -192,7 +199,7 @@ def pmc_traffic(argv_child, timeout_s=240):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable,
                    os.path.join(ROOT, "bench.py")] + argv_child
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", SE_FORK_DEFAULT="0")
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
@@ -294,10 +301,81 @@ def pin_rank(local_rank, local_world, dev_index):
         os.sched_setaffinity(0, sl)
     except OSError:
         return {"affinity": None}
-    threads = max(1, min(32, len(sl)))
+    # ... and never more than this rank's share of the CPUs the cgroup really grants (a 256-CPU host with a 16-CPU quota: eight
+    # ranks x 32 threads would only get every rank throttled)
+    from sketchedit_amd.hostinfo import effective_cpus
+    threads = max(1, min(32, len(sl), effective_cpus() // max(local_world, 1) or 1))
     torch.set_num_threads(threads)
     return {"affinity": "%d CPUs (%d..%d)" % (len(sl), sl[0], sl[-1]), "numa_node": node, "threads": threads,
             "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}
+
+
+def sysfs_gpus():
+    """AMD display / processing-accelerator PCI functions in bus order -- the order HIP enumerates them in by default -- with
+    their NUMA nodes, from sysfs alone (no HIP context): [(bdf, numa_node or None)]"""
+    out = []
+    base = "/sys/bus/pci/devices"
+    try:
+        for bdf in sorted(os.listdir(base)):
+            try:
+                with open(os.path.join(base, bdf, "vendor")) as f:
+                    if f.read().strip() != "0x1002":
+                        continue
+                with open(os.path.join(base, bdf, "class")) as f:
+                    cls = f.read().strip()
+                if not (cls.startswith("0x0302") or cls.startswith("0x0380") or cls.startswith("0x1200")):
+                    continue
+                with open(os.path.join(base, bdf, "numa_node")) as f:
+                    node = int(f.read().strip())
+                out.append((bdf, node if node >= 0 else None))
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        pass
+    return out
+
+
+def dry_run_topology(n, args):
+    """`--gpus N --dry-run-topology`: what the N ranks of a real run WOULD use -- GPU, NUMA node, CPU slice, thread budget,
+    rendezvous and RCCL environment, bytes of the one collective -- computed from sysfs without touching a GPU, so that the
+    first 8-GPU run is diagnosable from its inputs.  One JSON object on stdout."""
+    from sketchedit_amd.hostinfo import cgroup_cpu_quota, effective_cpus
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(os.cpu_count() or 1))
+    gpus = sysfs_gpus()
+    node_cpus = {}
+    for _, node in gpus:
+        if node is not None and node not in node_cpus:
+            try:
+                with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                    node_cpus[node] = parse_cpulist(f.read())
+            except (OSError, ValueError):
+                node_cpus[node] = None
+    ranks = []
+    for r in range(n):
+        bdf, node = gpus[r] if r < len(gpus) else (None, None)
+        cpus = node_cpus.get(node) if node is not None else None
+        peers = [q for q in range(n) if q < len(gpus) and gpus[q][1] == node] if cpus else None
+        sl = rank_cpu_slice(r, n, allowed, cpus, peers, key=cpu_core_key) if n > 1 else allowed
+        ranks.append({"rank": r, "local_rank": r, "hip_device": r, "gpu_pci": bdf, "numa_node": node,
+                      "cpu_affinity": "%d CPUs (%d..%d)" % (len(sl), sl[0], sl[-1]), "threads": max(1, min(32, len(sl), effective_cpus() // n or 1)),
+                      "shard": "images [%d, %d) of the global batch %d" % (r * args.batch, (r + 1) * args.batch, n * args.batch)})
+    env = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_MAX_NCHANNELS",
+                                          "NCCL_DEBUG", "MASTER_ADDR", "MASTER_PORT")}
+    return {"dry_run_topology": True, "n_gpus": n, "gpus_in_sysfs": len(gpus), "ranks": ranks,
+            "host": {"cpus_visible": os.cpu_count(), "cpus_allowed": len(allowed), "cgroup_cpu_quota": cgroup_cpu_quota(), "cpus_effective": effective_cpus()},
+            "launch": "one process per GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 ... bench.py --gpus %d "
+                      "(or `python bench.py --gpus %d`: self-launch, MASTER_ADDR=127.0.0.1, a free port)" % (n, n, n),
+            "backend": args.backend + (" (= RCCL over xGMI)" if args.backend == "nccl" else ""),
+            "visible_devices_policy": "not narrowed per rank: every rank sees every GPU and selects LOCAL_RANK (RCCL's P2P transport needs the peers visible); "
+                                      "a caller-set HIP_VISIBLE_DEVICES is honoured",
+            "environment": dict(env, NCCL_MAX_NCHANNELS_would_be=(str(args.nccl_channels) if args.nccl_channels > 0 else env["NCCL_MAX_NCHANNELS"]),
+                                HSA_ENABLE_IPC_MODE_LEGACY_required="0 (dmabuf IPC: RCCL / cross-process device memory fail without it on these hosts)"),
+            "collective": {"what": "ONE all_gather_into_tensor of the packed (B,4,H,W) outputs per step" + ("" if args.no_overlap else ", on a side stream under the next forward"),
+                           "bytes_per_rank_per_step": args.batch * 4 * args.size * args.size * 4,
+                           "bytes_gathered_per_rank_per_step": n * args.batch * 4 * args.size * args.size * 4}}
 
 
 def self_launch(n):
@@ -593,6 +671,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather on the compute stream instead of a side stream")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gather even with one rank")
     ap.add_argument("--nccl-channels", type=int, default=0, help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS); 0 = RCCL's own choice")
+    ap.add_argument("--dry-run-topology", action="store_true", help="print what the --gpus N ranks WOULD use (GPU, NUMA slice, threads, RCCL / rendezvous environment) and exit; needs no GPU")
     ap.add_argument("--e2e", action="store_true", help="only the end-to-end leg: PNG files -> test.py's pipelined loop -> PNG files (one JSON line)")
     ap.add_argument("--e2e-images", type=int, default=4000, help="list entries of the e2e leg (symlinks over --e2e-unique files)")
     ap.add_argument("--e2e-unique", type=int, default=1000, help="unique synthetic PNG pairs generated on tmpfs")
@@ -605,6 +684,9 @@ def main():
     ap.add_argument("--e2e-cap-seconds", type=float, default=3.0, help="seconds per host-codec capability leg (decode, encode, both)")
     ap.add_argument("--no-e2e", action="store_true", help="default invocation: skip the end-to-end child run")
     args = ap.parse_args()
+    if args.dry_run_topology:
+        os.write(real_stdout, (json.dumps(dry_run_topology(max(1, args.gpus), args)) + "\n").encode())
+        return
     if args.e2e:
         line = e2e_leg(args)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
@@ -789,6 +871,10 @@ def main():
                     "frac_algorithmic": round(algorithmic / peak, 4),
                     "traffic": None, "traffic_source": None,
                     "achieved_is": "executed multiply-add FLOPs per launch / average launch duration (HIP events)",
+                    # the timed headline overlaps the independent branches of netG on two streams; a per-launch duration is a
+                    # property of one kernel only when nothing else shares the chip, so this pass (and the rocprofv3 child passes)
+                    # runs the same kernels on ONE stream
+                    "measured_with": "branches serialised (profiler pass: one stream); the timed region runs the two-stream plan",
                     "algorithmic_tflops": round(algorithmic, 3),
                     "executed_over_algorithmic": round(dom["flops_executed"] / dom["flops"], 4),
                     "launches_per_step": dom["launches"] // nprof,
@@ -881,7 +967,8 @@ def main():
             "config": {"workload": "SketchEdit inference forward (netM+netG, use_cam, pool max) %dx%d batch %d per GPU, "
                                    "procedural weights" % (S, S, B),
                        "global_batch": world * B, "size": S, "per_gpu_batch": B,
-                       "execution": ("low-latency" if ll_on else "default") + ("+graph" if args.graph else ""),
+                       "execution": ("low-latency" if ll_on else "default") + ("+graph" if args.graph else "") +
+                                    ("" if ll_on else (", two streams" if _lib_opt("SE_FORK_DEFAULT") else ", one stream")),
                        "host_placement_rank0": placement,
                        "collective": ({"what": "one all_gather of the packed (B,4,H,W) outputs per step" +
                                                (" on a side stream, under the next step's forward" if overlap else ""),

@@ -157,6 +157,7 @@ struct se_ctx {
   bool low_latency = false; // SE_FLAG_LOW_LATENCY of the running call
   int cur_net = SE_NET_G;   // network whose plan is running (plan_netM / plan_netG; per-op entry points: G)
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
+  bool serial = false;             // default mode on one stream (set while the profiler is on: per-kernel durations)
   bool conservative = false;       // SE_FLAG_CONSERVATIVE of the running call: netM's 96 -> 192 layers on F(2x2,3x3)
   const se_netG_taps* taps = nullptr;      // se_netG_forward_taps: intermediate outputs of the running netG plan
   float* vbias_ws = nullptr;       // [B][9][192] scratch for the folded vector source of the next two-source layer (plan_netG)
@@ -166,6 +167,8 @@ struct se_ctx {
   Profiler prof;
   struct Peaks { size_t main, side; };
   std::map<std::vector<long long>, Peaks> peaks;      // dry-run arena peaks per (B, H, W, flags, outputs wanted)
+  size_t dry_max_act = 0;                             // dry runs: bytes of the largest activation tensor the plan allocated
+  std::map<std::vector<long long>, long long> act_per_img;      // (H, W, bf16) -> bytes per image of the largest activation
   struct GraphEntry {
     std::vector<long long> key;
     hipGraph_t graph = nullptr;
@@ -1415,6 +1418,7 @@ struct Plan {
       a.C = C;
       a.p = alloc_raw((size_t)B * H * W * C);
     }
+    if (c->dry) c->dry_max_act = std::max(c->dry_max_act, (size_t)B * H * W * a.C * (c->bf16 ? 2 : 4));
     return a;
   }
   void release(const float* p) {          // to whichever arena the block came from
@@ -1426,8 +1430,10 @@ struct Plan {
   // side arena; it starts after everything enqueued on the main stream so far (fork event) and join() makes the main
   // stream wait for it.  A buffer shared by both branches must be released only after join().  Outside low-latency mode
   // the calls do nothing: the branch is planned in line, on the main stream and arena.
-  // (SE_FORK_DEFAULT=1: the two-stream plan in the default mode too -- an A/B switch, measured in round 6: DESIGN.md 7b)
-  bool forked() const { return (c->low_latency || opt(OPT_FORK_DEFAULT) != 0) && c->st_side; }
+  // Default mode (round 6): the same two-stream plan (SE_FORK_DEFAULT=0: one stream) -- the tail of one branch's kernel runs
+  // under the head of the other's: +2 % on configs 2, 3 and 5.  While the in-library profiler is on, the default mode is
+  // planned on ONE stream (c->serial): an event pair around a launch measures that kernel only when nothing else shares the chip.
+  bool forked() const { return (c->low_latency || (opt(OPT_FORK_DEFAULT) != 0 && !c->serial)) && c->st_side; }
   int side_begin() {
     if (!forked()) return 0;
     ar = &c->arena2;
@@ -1711,13 +1717,36 @@ int check_dims(se_ctx* c, int B, int H, int W) {
 
 // Passes of a forward over a large batch.  The kernels address a tensor with 32-bit byte offsets (addr_limit); the largest
 // tensor of either network is the 24-channel full-resolution activation (conv1 / conv15_upsample outputs: 96 bytes per
-// pixel in fp32, 48 in bf16), so a forward runs over at most (limit - 1) / (H W 96) images at a time and a larger batch is
+// pixel in fp32, 48 in bf16 -- max_act_bytes_per_image derives it from the plans), so a forward runs over at most
+// (limit - 1) / (H W 96) images at a time and a larger batch is
 // run as several passes of the SAME plan over image ranges -- same kernels, same execution mode, so an image's result does
 // not depend on the pass it lands in (bit for bit: test_large_batch_is_split_into_passes).  Passes are balanced
 // (ceil(B / passes) images each).  Returns the images per pass, or 0 (error set) when ONE image exceeds the range.
+// bytes per image of the LARGEST activation tensor either plan allocates at this size -- derived from a dry run of the plans
+// themselves (the literal "24 channels at full resolution = 96 / 48 bytes per pixel" would silently go stale with
+// a wider layer); cached per (H, W, precision)
+long long max_act_bytes_per_image(se_ctx* c, int H, int W, int flags) {
+  const std::vector<long long> key = {H, W, (flags & SE_FLAG_BF16) ? 1 : 0};
+  auto it = c->act_per_img.find(key);
+  if (it != c->act_per_img.end()) return it->second;
+  const bool dry0 = c->dry, ll0 = c->low_latency, bf0 = c->bf16;
+  c->dry = true; c->low_latency = false; c->bf16 = (flags & SE_FLAG_BF16) != 0;
+  c->dry_max_act = 0;
+  float dummy;
+  c->arena.reset(nullptr, 0, true, 0); c->arena2.reset(nullptr, 0, true, 1);
+  plan_netM(c, nullptr, nullptr, nullptr, nullptr, &dummy, 1, H, W, 0);
+  c->arena.reset(nullptr, 0, true, 0); c->arena2.reset(nullptr, 0, true, 1);
+  plan_netG(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, H, W, SE_FLAG_USE_CAM | SE_FLAG_POOL_MAX, 0);
+  c->dry = dry0; c->low_latency = ll0; c->bf16 = bf0;
+  const long long v = (long long)c->dry_max_act;
+  c->act_per_img[key] = v;
+  return v;
+}
+
 int pass_size(se_ctx* c, int B, int H, int W, int flags) {
-  const long long per_img = (long long)H * W * ((flags & SE_FLAG_BF16) ? 48 : 96);
+  const long long per_img = max_act_bytes_per_image(c, H, W, flags);
   const long long lim = addr_limit();
+  if (per_img <= 0) { fail(c, "internal: no activation size for %dx%d", H, W); return 0; }
   if (per_img >= lim) {
     fail(c, "a %dx%d image exceeds the kernels' 32-bit byte offsets (%lld bytes per activation, limit %lld)", H, W, per_img, lim);
     return 0;
@@ -1733,7 +1762,7 @@ int pass_size(se_ctx* c, int B, int H, int W, int flags) {
 se_ctx::Peaks plan_peaks(se_ctx* c, int which, int B, int H, int W, int flags, bool want_maskim) {
   const std::vector<long long> key = {which, B, H, W,
                                       flags & (SE_FLAG_USE_CAM | SE_FLAG_JOINT_TRAIN_INP | SE_FLAG_LOW_LATENCY | SE_FLAG_BF16),
-                                      want_maskim ? 1 : 0, attention_v2_enabled() ? 1 : 0, opt_epoch()};
+                                      want_maskim ? 1 : 0, attention_v2_enabled() ? 1 : 0, opt_epoch(), c->serial ? 1 : 0};
   auto it = c->peaks.find(key);
   if (it != c->peaks.end()) return it->second;
   const bool dry0 = c->dry, ll0 = c->low_latency, bf0 = c->bf16;
@@ -1774,6 +1803,7 @@ void begin_call(se_ctx* c, void* stream, int flags) {
   c->low_latency = (flags & SE_FLAG_LOW_LATENCY) != 0;
   c->bf16 = (flags & SE_FLAG_BF16) != 0;
   c->conservative = (flags & SE_FLAG_CONSERVATIVE) != 0;
+  c->serial = c->prof.on;
   c->taps = nullptr;
   c->rgb8 = nullptr; c->m8 = nullptr;
   c->cur_net = SE_NET_G;       // per-op entry points run as netG layers whatever plan ran last; the plans set their own
@@ -1962,12 +1992,16 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
           if (!nb) return 0;
           const int last = B % nb;                      // size of a ragged last pass (0: none)
           // with and without netM's image decoder (mode='visualize' vs 'inference'): two allocation sequences
-          for (int mi = 0; mi < 2; ++mi)
-            for (int bb : {nb, last}) {
-              if (!bb) continue;
-              const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, mi != 0);
-              if (pk.main + pk.side > peak) peak = pk.main + pk.side;
-            }
+          // ... each on two streams and on one (the profiler's plan of the default mode: c->serial)
+          for (int ser = 0; ser < 2; ++ser)
+            for (int mi = 0; mi < 2; ++mi)
+              for (int bb : {nb, last}) {
+                if (!bb) continue;
+                c->serial = ser != 0;
+                const se_ctx::Peaks pk = plan_peaks(c, 3, bb, H, W, flags, mi != 0);
+                if (pk.main + pk.side > peak) peak = pk.main + pk.side;
+              }
+          c->serial = false;
         }
   // + hard-mask (se_inference) and soft-mask (se_inference_u8) planes + the fp32 image / sketch of se_inference_u8io (4 planes)
   return peak + 6 * (((size_t)B * H * W * 4 + 255) & ~(size_t)255);
@@ -1980,6 +2014,7 @@ int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float*
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
+  c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
   exec_flags &= SE_FLAG_LOW_LATENCY | SE_FLAG_BF16 | SE_FLAG_CONSERVATIVE;
   const int nb = pass_size(c, B, H, W, exec_flags);
   if (!nb) return 1;
@@ -2008,6 +2043,7 @@ int se_netG_forward_taps(se_ctx* c, void* stream, const float* x, const float* x
   if (check_dims(c, B, H, W)) return 1;
   if (!x || !x2 || !mask || !mask2 || !guide || !fine_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
+  c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
   const int nb = pass_size(c, B, H, W, flags);
   if (!nb) return 1;
   if (taps && nb < B) return fail(c, "se_netG_forward_taps: %d images do not fit one pass (%d)", B, nb);
@@ -2074,6 +2110,7 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !composed_out || (!mask_out && !(flags & SE_FLAG_PACKED_OUT)) || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
+  c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
   if (!(flags & SE_FLAG_GRAPH) || c->prof.on)
     return enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out, fine_out, ws,
                              ws_bytes, B, H, W, flags);
@@ -2158,6 +2195,7 @@ int se_inference_u8(se_ctx* c, void* stream, const float* image, const float* sk
   if (check_dims(c, B, H, W)) return 1;
   if (!image || !sketch || !rgb_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
+  c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
   return inference_u8_locked(c, stream, image, sketch, rgb_out, mask_u8_out, ws, ws_bytes, B, H, W, flags, 0);
 }
 
@@ -2183,6 +2221,7 @@ int se_inference_u8io(se_ctx* c, void* stream, const unsigned char* image_u8, co
   if (check_dims(c, B, H, W)) return 1;
   if (!image_u8 || !sketch_u8 || !rgb_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
+  c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
   const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
   if (ws_bytes < 6 * plane) return fail(c, "workspace too small: %zu bytes", ws_bytes);
   float* image = (float*)((char*)ws + ws_bytes - 4 * plane);      // (B,3,H,W) contiguous: 3 B H W floats <= 3 planes

@@ -904,6 +904,28 @@ def test_batch_beyond_2_gib_of_activation_256(eng_w):
         torch.cuda.empty_cache()
 
 
+def test_batch_beyond_2_gib_of_activation_256_bf16(eng_w):
+    """the bf16 mode at ITS real limit -- 48 bytes per pixel of the largest activation, 682 images of 256x256 in
+    one pass (2,145,386,496 bytes), 684 as 342 + 342 -- first, last and the images either side of the pass boundary equal
+    their single-image results bit for bit."""
+    img1, sk1 = synth.make_inputs(6, 256, 256, seed=2025)
+    eng_w.set_precision("bf16")
+    try:
+        for B in (682, 684):
+            idx = np.arange(B) % 6
+            ci, cs = _cuda(img1[idx]), _cuda(sk1[idx])
+            out = eng_w.inference_packed(ci, cs, FLAGS, torch.empty((B, 4, 256, 256), device="cuda"), low_latency=False)
+            for k in (0, 341, 342, B - 1):
+                j = int(idx[k])
+                one = eng_w.inference(_cuda(img1[j:j + 1]), _cuda(sk1[j:j + 1]), FLAGS, low_latency=False)
+                assert torch.equal(out[k:k + 1, 0:3], one["composed"]), (B, k)
+                assert torch.equal(out[k:k + 1, 3:4], one["mask"]), (B, k)
+            del out, ci, cs
+            torch.cuda.empty_cache()
+    finally:
+        eng_w.set_precision("f32")
+
+
 def test_per_op_call_beyond_2_gib_is_an_error(eng):
     """The per-op entry points do not split: a 24-channel fp32 source of 342 x 256 x 256 pixels (2^31 + 4.2 MB bytes) is
     refused with a message, where the round-4 guards (which counted ELEMENTS) let the kernel run with a wrapped

@@ -616,3 +616,20 @@ def test_effective_cpus_honours_a_cgroup_quota(monkeypatch, tmp_path):
     assert hostinfo.effective_cpus() == min(2, len(os.sched_getaffinity(0)))
     monkeypatch.setattr(hostinfo, "cgroup_cpu_quota", lambda: 0.5)
     assert hostinfo.effective_cpus() == 1
+
+
+def test_bench_dry_run_topology_needs_no_gpu():
+    """`bench.py --gpus 8 --dry-run-topology`: the per-rank placement and environment a real 8-GPU run
+    would use, from sysfs alone -- runs here, where there is no GPU: contiguous CPU slices, every rank's shard of the global
+    batch, the one collective's byte counts."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-topology", "--nccl-channels", "4"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["dry_run_topology"] and d["n_gpus"] == 8 and len(d["ranks"]) == 8
+    assert [r["hip_device"] for r in d["ranks"]] == list(range(8))
+    assert d["ranks"][7]["shard"] == "images [224, 256) of the global batch 256"
+    assert d["collective"]["bytes_per_rank_per_step"] == 32 * 4 * 256 * 256 * 4
+    assert d["environment"]["NCCL_MAX_NCHANNELS_would_be"] == "4"
+    assert all(r["threads"] >= 1 for r in d["ranks"]) and d["host"]["cpus_effective"] >= 1

@@ -15,6 +15,13 @@ Q="--no-cpu-baseline --no-parity --no-traffic --no-secondary"
 profile() {   # name, bench args
   name=$1; shift
   cd /tmp
+  # one un-instrumented trace of the DEFAULT (two-stream) plan first: launch order and overlap as the timed region runs them
+  timeout 300 rocprofv3 --kernel-trace -d $out/${name}_seq2 --output-format csv -- python $root/bench.py $* --steps 1 --warmup 1 $Q > /dev/null 2> $out/${name}_seq2.err
+  python $root/tools/kernel_seq.py $(find $out/${name}_seq2 -name "*kernel_trace.csv" | head -1) > $out/${name}_kernel_seq_two_streams.txt 2>> $out/${name}_seq2.err
+  rm -rf $out/${name}_seq2
+  # every per-kernel measurement below runs the same kernels on ONE stream (SE_FORK_DEFAULT=0): a launch duration / byte count is
+  # a property of one kernel only when nothing else shares the chip
+  export SE_FORK_DEFAULT=0
   B="python $root/bench.py $* --steps 5 --warmup 2 $Q"
   timeout 300 rocprofv3 --kernel-trace --stats -d $out/${name}_prof -o $name -- $B > $out/${name}_bench_under_rocprof.json 2> $out/${name}_prof.err
   P="python $root/bench.py $* --steps 1 --warmup 1 $Q"
@@ -36,6 +43,7 @@ profile() {   # name, bench args
   done
   python tools/pmc_summary.py --json $out/${name}_pmc_traffic.json $flat > $out/${name}_pmc_summary.txt
   find $out -name "*.db" -delete; rm -rf $out/${name}_pmc1 $out/${name}_pmc2 $out/${name}_pmc3 $out/${name}_pmc?_flat $out/${name}_prof
+  unset SE_FORK_DEFAULT
 }
 cd $root
 for cfg in $cfgs; do
