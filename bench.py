@@ -575,8 +575,9 @@ def e2e_leg(args):
             thr0 = cgroup_throttle_stats()
             loader = data.create_dataloader(opt)
             pipe = InferencePipeline(model, opt.output_dir, None, encode_threads=e, depth=args.e2e_depth, timing=True, verbose=False,
-                                     encode_procs=0 if args.e2e_encode_threads else e, max_pending_batches=args.e2e_pending, png_writer=writer)
-            st = dict(pipe.run(loader, float("inf"), B))
+                                     encode_procs=0 if args.e2e_encode_threads else e, max_pending_batches=args.e2e_pending, png_writer=writer,
+                                     decode_procs=0 if args.e2e_dataloader else w)
+            st = dict(pipe.run(loader, float("inf"), B) if args.e2e_dataloader else pipe.run_paths(loader.dataset, float("inf"), B))
             pipe.close()
             thr1 = cgroup_throttle_stats()
             img = st["images"]
@@ -594,6 +595,7 @@ def e2e_leg(args):
             legs[writer] = {
                 "e2e_images_per_sec": round(e2e, 1), "images": img, "files_written": len(os.listdir(opt.output_dir)), "wall_s": round(st["wall_s"], 3),
                 "decode_workers": w, "encode_workers": e, "encoders_are": "threads" if args.e2e_encode_threads else "processes",
+                "decoders_are": "DataLoader workers" if args.e2e_dataloader else "processes writing into the shared page-locked input ring",
                 # standalone rate of every stage (images/sec): decode = the host alone at this worker count (no GPU), encode = the
                 # encoder processes alone on an image the network produced;
                 # h2d / forward / d2h = images / summed HIP-event time of that stage inside the pipelined run
@@ -613,7 +615,7 @@ def e2e_leg(args):
                                                                           "throttled_thread_seconds": round((thr1[2] - thr0[2]) * 1e-6, 3)})}
         main_leg = legs["pil"]
         line = {"metric": "e2e_images_per_sec", "value": main_leg["e2e_images_per_sec"], "unit": "images/sec", "size": S, "batch": B,
-                "what": "test.py's loop, files to files: PNG pair on tmpfs -> decode (worker processes) -> page-locked uint8 ring -> H2D -> "
+                "what": "test.py's loop, files to files: PNG pair on tmpfs -> decode (worker processes, straight into a shared page-locked uint8 ring) -> H2D -> "
                         "se_inference_u8io -> D2H into a shared page-locked ring -> PNG encode + write (worker processes); %d list entries "
                         "over %d unique synthetic pairs.  value = the `pil` writer (PIL defaults: the files this repo always wrote); `fast` = the "
                         "reference's cv2.imwrite settings (SUB filter, zlib 1, RLE), same pixels" % (N, U),
@@ -680,6 +682,7 @@ def main():
     ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight on the device")
     ap.add_argument("--e2e-reserve", type=int, default=-1, help="CPUs left to the main process (-1: a fifth of the effective CPUs)")
     ap.add_argument("--e2e-pending", type=int, default=8, help="batches that may wait for their encoders")
+    ap.add_argument("--e2e-dataloader", action="store_true", help="decode in DataLoader workers (--nThreads) instead of the pipeline's own decoder processes")
     ap.add_argument("--e2e-encode-threads", action="store_true", help="encoder THREADS in the main process instead of processes (GIL-bound near 2000 images/s)")
     ap.add_argument("--e2e-cap-seconds", type=float, default=3.0, help="seconds per host-codec capability leg (decode, encode, both)")
     ap.add_argument("--no-e2e", action="store_true", help="default invocation: skip the end-to-end child run")

@@ -35,7 +35,7 @@ from .png_worker import save_png  # noqa: F401  (also test.py's serial loop)
 
 
 class _EncoderProcs:
-    """`n` encoder processes (`python -m sketchedit_amd.png_worker`: numpy + PIL only, no torch, no HIP state -- plain child
+    """`n` codec processes (encoders; the same class runs the decoders of InferencePipeline.run_paths) (`python -m sketchedit_amd.png_worker`: numpy + PIL only, no torch, no HIP state -- plain child
     processes, nothing forked from this one).  submit(job) -> Future of the seconds the job took; a job goes to the worker with
     the fewest outstanding jobs; ONE reader thread collects the completion lines."""
 
@@ -106,7 +106,7 @@ class _EncoderProcs:
 
 
 class _Batch:
-    __slots__ = ("paths", "n", "slot_in", "slot_out", "dev", "ev0", "ev_h2d", "ev_fwd0", "ev_fwd", "ev_d2h", "futs", "shape")
+    __slots__ = ("paths", "n", "slot_in", "slot_out", "dev", "ev0", "ev_h2d", "ev_fwd0", "ev_fwd", "ev_d2h", "futs", "shape", "rings", "dfuts")
 
 
 class _PinnedRing:
@@ -152,7 +152,7 @@ class InferencePipeline:
     fed through a shared page-locked ring instead."""
 
     def __init__(self, model, out_dir, mask_dir=None, encode_threads=1, depth=2, low_latency=None, max_pending_batches=6,
-                 timing=False, verbose=True, encode=True, encode_procs=0, png_writer="pil"):
+                 timing=False, verbose=True, encode=True, encode_procs=0, png_writer="pil", decode_procs=0, decode_ahead=4):
         self.model, self.out_dir, self.mask_dir = model, out_dir, mask_dir
         self.depth, self.low_latency, self.verbose, self.encode = max(1, depth), low_latency, verbose, encode
         # never more intra-op threads than the CPUs this process is granted (affinity AND cgroup quota): on a 256-CPU host with a
@@ -171,6 +171,10 @@ class InferencePipeline:
             self.procs = _EncoderProcs(int(encode_procs))
         else:
             self.pool = ThreadPoolExecutor(max(1, int(encode_threads)), thread_name_prefix="png")
+        # decode_procs > 0: run_paths() decodes with that many worker processes straight into a shared page-locked input ring
+        # (no DataLoader: nothing is pickled, collated or staged) `decode_ahead` batches ahead of the device
+        self.dprocs = _EncoderProcs(int(decode_procs)) if decode_procs > 0 else None
+        self.decode_ahead = max(1, int(decode_ahead))
         self.rings = {}            # (kind, shape) -> _PinnedRing
         self.stats = {"images": 0, "batches": 0, "decode_wait_s": 0.0, "h2d_ms": 0.0, "forward_ms": 0.0, "d2h_ms": 0.0,
                       "encode_cpu_s": 0.0, "sync_wait_s": 0.0, "encode_backpressure_s": 0.0,
@@ -187,26 +191,36 @@ class InferencePipeline:
 
     # ---- device side ---------------------------------------------------------------------------------------------
     def _enqueue(self, data_i, pending):
+        """a DataLoader batch (u8 mode): stage it into the page-locked input ring, then hand it to the device"""
         b = _Batch()
         b.paths = list(data_i["path"])
         iu8, su8 = data_i["image_u8"], data_i["mask_u8"]
         b.n = iu8.shape[0]
         b.shape = tuple(iu8.shape)
-        H, W = iu8.shape[1:3]
-        ll = self.low_latency if self.low_latency is not None else self.model.batch_mode(H, W)
-        nin, nout = self.depth + 2, self.depth + self.max_pending + 2
+        nin = self.depth + 2
         rin_i, rin_s = self._ring("in_i", iu8.shape, nin), self._ring("in_s", su8.shape, nin)
-        shared = self.procs is not None
-        rout = self._ring("out_rgb", iu8.shape, nout, shared)
-        rout_m = self._ring("out_m8", su8.shape, nout, shared) if self.mask_dir is not None else None
         t0 = time.perf_counter()
         b.slot_in = rin_i.free.popleft()
+        np.copyto(rin_i.t[b.slot_in].numpy(), iu8.numpy())           # staging copy into page-locked memory: one thread, ~1 ms for 8 MB
+        np.copyto(rin_s.t[b.slot_in].numpy(), su8.numpy())
+        self.stats["issue_stage_s"] += time.perf_counter() - t0
+        return self._to_device(b, rin_i, rin_s, pending)
+
+    def _to_device(self, b, rin_i, rin_s, pending):
+        """H2D of input slot b.slot_in (first b.n images), forward, D2H into an output slot: three streams, events only"""
+        H, W = b.shape[1:3]
+        ll = self.low_latency if self.low_latency is not None else self.model.batch_mode(H, W)
+        nout = self.depth + self.max_pending + 2
+        shared = self.procs is not None
+        full = (rin_i.shape[0],) + tuple(b.shape[1:])                # ring slots hold a FULL batch; a ragged last one uses a prefix
+        rout = self._ring("out_rgb", full, nout, shared)
+        rout_m = self._ring("out_m8", full[:3], nout, shared) if self.mask_dir is not None else None
+        t0 = time.perf_counter()
         while not rout.free:                         # every output slot is with the encoders: wait for the oldest batch
             self._release_oldest(pending)
         b.slot_out = rout.free.popleft()
-        hi, hs = rin_i.t[b.slot_in], rin_s.t[b.slot_in]
-        np.copyto(hi.numpy(), iu8.numpy())           # staging copy into page-locked memory: one thread, ~1 ms for 8 MB
-        np.copyto(hs.numpy(), su8.numpy())
+        self.stats["issue_stage_s"] += time.perf_counter() - t0
+        hi, hs = rin_i.t[b.slot_in][: b.n], rin_s.t[b.slot_in][: b.n]
         mk = lambda: torch.cuda.Event(enable_timing=self.timing)      # noqa: E731
         b.ev_h2d, b.ev_fwd0, b.ev_fwd, b.ev_d2h = mk(), mk(), mk(), mk()
         b.ev0 = mk() if self.timing else None
@@ -225,14 +239,15 @@ class InferencePipeline:
         t3 = time.perf_counter()
         with torch.cuda.stream(self.s_d2h):
             self.s_d2h.wait_event(b.ev_fwd)
-            rout.t[b.slot_out].copy_(rgb, non_blocking=True)
+            rout.t[b.slot_out][: b.n].copy_(rgb, non_blocking=True)
             if rout_m is not None:
-                rout_m.t[b.slot_out].copy_(m8, non_blocking=True)
+                rout_m.t[b.slot_out][: b.n].copy_(m8, non_blocking=True)
             b.ev_d2h.record(self.s_d2h)
         b.dev = (di, ds, rgb, m8)                    # device tensors stay alive until the batch has retired
+        b.rings = (rin_i, rout, rout_m)
         t4 = time.perf_counter()
         st = self.stats
-        st["issue_stage_s"] += t1 - t0; st["issue_h2d_s"] += t2 - t1; st["issue_forward_s"] += t3 - t2; st["issue_d2h_s"] += t4 - t3
+        st["issue_h2d_s"] += t2 - t1; st["issue_forward_s"] += t3 - t2; st["issue_d2h_s"] += t4 - t3
         return b
 
     # ---- host side -----------------------------------------------------------------------------------------------
@@ -251,7 +266,7 @@ class InferencePipeline:
             r = f.result()                                             # re-raises an encoder's exception
             if self.procs is not None:
                 self.stats["encode_cpu_s"] += r
-        self.rings[("out_rgb", b.shape)].free.append(b.slot_out)
+        b.rings[1].free.append(b.slot_out)
 
     def _retire(self, b, pending):
         t0 = time.perf_counter()
@@ -261,10 +276,9 @@ class InferencePipeline:
             self.stats["h2d_ms"] += b.ev0.elapsed_time(b.ev_h2d)
             self.stats["forward_ms"] += b.ev_fwd0.elapsed_time(b.ev_fwd)
             self.stats["d2h_ms"] += b.ev_fwd.elapsed_time(b.ev_d2h)
-        self.rings[("in_i", b.shape)].free.append(b.slot_in)
+        b.rings[0].free.append(b.slot_in)
         b.dev = None
-        rout = self.rings[("out_rgb", b.shape)]
-        rout_m = self.rings.get(("out_m8", b.shape[:3]))
+        rout, rout_m = b.rings[1], b.rings[2]
         b.futs = []
         t0 = time.perf_counter()
         if self.verbose:
@@ -278,8 +292,8 @@ class InferencePipeline:
                     mask_shape=((rout_m.n,) + rout_m.shape) if rout_m else None, slot=b.slot_out, first=first,
                     paths=b.paths[first:first + chunk], out_dir=self.out_dir, mask_dir=self.mask_dir, writer=self.png_writer)))
         elif self.encode:
-            rgb = rout.t[b.slot_out].numpy()
-            m8 = rout_m.t[b.slot_out].numpy() if rout_m is not None else None
+            rgb = rout.t[b.slot_out][: b.n].numpy()
+            m8 = rout_m.t[b.slot_out][: b.n].numpy() if rout_m is not None else None
             for i, path in enumerate(b.paths):
                 b.futs.append(self.pool.submit(self._encode_job, rgb[i], None if m8 is None else m8[i], path))
         self.stats["submit_encode_s"] += time.perf_counter() - t0
@@ -319,7 +333,67 @@ class InferencePipeline:
         self.stats["wall_s"] = time.perf_counter() - t_start
         return self.stats
 
+    def run_paths(self, dataset, how_many=float("inf"), batch_size=1):
+        """The same loop fed by this pipeline's own decode processes instead of a DataLoader: `dataset` supplies the path lists
+        (data/testimage_dataset.py: image_paths, mask_paths, output_paths; serial order); the workers decode straight into a
+        shared page-locked ring (hipHostRegister'ed /dev/shm file), `decode_ahead` batches ahead of the device.  Stops like
+        test.py:21-22."""
+        from PIL import Image
+        assert self.dprocs is not None, "run_paths needs decode_procs > 0"
+        n = len(dataset.image_paths)
+        starts = [k for i, k in enumerate(range(0, n, batch_size)) if i * batch_size < how_many]
+        decoding, inflight, pending = deque(), deque(), deque()
+        t_start = time.perf_counter()
+        nd = len(self.dprocs.ws)
+
+        def submit_decode(k):
+            b = _Batch()
+            idx = list(range(k, min(k + batch_size, n)))
+            b.paths = [dataset.output_paths[i] for i in idx]
+            b.n = len(idx)
+            with Image.open(dataset.image_paths[k]) as im:      # header only: the batch's image size
+                W, H = im.size
+            b.shape = (b.n, H, W, 3)
+            nin = self.depth + self.decode_ahead + 2
+            rin_i = self._ring("in_i", (batch_size, H, W, 3), nin, True)
+            rin_s = self._ring("in_s", (batch_size, H, W), nin, True)
+            b.slot_in = rin_i.free.popleft()
+            b.rings = (rin_i, rin_s)
+            chunk = max(1, -(-b.n // max(1, min(b.n, 2 * nd))))
+            b.dfuts = [self.dprocs.submit(dict(kind="decode", img_ring=rin_i.path, img_shape=(rin_i.n,) + rin_i.shape, sk_ring=rin_s.path,
+                                               sk_shape=(rin_s.n,) + rin_s.shape, slot=b.slot_in, first=f,
+                                               image_paths=[dataset.image_paths[i] for i in idx[f:f + chunk]],
+                                               mask_paths=[dataset.mask_paths[i] for i in idx[f:f + chunk]]))
+                       for f in range(0, b.n, chunk)]
+            return b
+
+        nxt = 0
+        while nxt < len(starts) or decoding:
+            while nxt < len(starts) and len(decoding) < self.decode_ahead:
+                decoding.append(submit_decode(starts[nxt]))
+                nxt += 1
+            b = decoding.popleft()
+            t0 = time.perf_counter()
+            for f in b.dfuts:
+                self.stats["decode_cpu_s"] = self.stats.get("decode_cpu_s", 0.0) + f.result()      # re-raises a decoder's exception
+            self.stats["decode_wait_s"] += time.perf_counter() - t0
+            if len(inflight) > self.depth:
+                self._retire(inflight.popleft(), pending)
+            rin_i, rin_s = b.rings
+            inflight.append(self._to_device(b, rin_i, rin_s, pending))
+        while inflight:
+            self._retire(inflight.popleft(), pending)
+        t0 = time.perf_counter()
+        while pending:
+            self._release_oldest(pending)
+        self.stats["encode_drain_s"] = time.perf_counter() - t0
+        self.stats["wall_s"] = time.perf_counter() - t_start
+        return self.stats
+
     def close(self):
+        if self.dprocs is not None:
+            self.dprocs.close()
+            self.dprocs = None
         if self.pool is not None:
             self.pool.shutdown(wait=True)
         if self.procs is not None:

@@ -75,6 +75,35 @@ def encode_from_ring(job):
     return time.perf_counter() - t0
 
 
+_wmaps = {}
+
+
+def _ring_rw(path, shape):
+    key = (path, tuple(shape))
+    m = _wmaps.get(key)
+    if m is None:
+        m = _wmaps[key] = np.memmap(path, dtype=np.uint8, mode="r+", shape=tuple(shape))
+    return m
+
+
+def decode_into_ring(job):
+    """job: dict(img_ring, img_shape, sk_ring, sk_shape, slot, first, image_paths, mask_paths): decode pairs as the dataset does
+    (/root/reference/data/testimage_dataset.py:89-111: RGB; sketch 'L' resized to the image) straight into slot `slot` of the
+    page-locked input rings, images first .. first + n - 1 -> seconds spent.  The ring fixes the batch's image size."""
+    t0 = time.perf_counter()
+    img = _ring_rw(job["img_ring"], job["img_shape"])[job["slot"]]
+    sk = _ring_rw(job["sk_ring"], job["sk_shape"])[job["slot"]]
+    H, W = img.shape[1:3]
+    for j, (ip, mp) in enumerate(zip(job["image_paths"], job["mask_paths"])):
+        image = Image.open(ip).convert("RGB")
+        w, h = image.size
+        if (h, w) != (H, W):
+            raise ValueError("%s is %dx%d, the batch is %dx%d (images of one batch must have one size)" % (ip, h, w, H, W))
+        img[job["first"] + j] = np.asarray(image, dtype=np.uint8)
+        sk[job["first"] + j] = np.asarray(Image.open(mp).convert("L").resize((w, h)), dtype=np.uint8)
+    return time.perf_counter() - t0
+
+
 def main():
     out = sys.stdout
     out.write("ready %d\n" % os.getpid())
@@ -85,7 +114,7 @@ def main():
             continue
         job = json.loads(line)
         try:
-            out.write("done %d %.6f\n" % (job["id"], encode_from_ring(job)))
+            out.write("done %d %.6f\n" % (job["id"], decode_into_ring(job) if job.get("kind") == "decode" else encode_from_ring(job)))
         except Exception as e:      # noqa: BLE001  (reported to the parent, which raises it in the caller's thread)
             out.write("fail %d %s\n" % (job["id"], json.dumps("%s: %s" % (type(e).__name__, e))))
         out.flush()

@@ -285,14 +285,19 @@ def test_pipelined_test_py_writes_the_serial_loops_files(tmp_path):
     _run_test_py((base + "--nThreads 2 --encode_procs 2 --output_dir {d}/r --output_mask_dir {d}/rm".format(d=tmp_path)).split())
     # the reference's cv2.imwrite settings written directly: other bytes, the same pixels
     _run_test_py((base + "--nThreads 1 --encode_procs 2 --png_writer fast --output_dir {d}/f --output_mask_dir {d}/fm".format(d=tmp_path)).split())
+    # the pipeline's own decoder processes (shared page-locked INPUT ring) in front of encoder processes
+    _run_test_py((base + "--decode_procs 2 --encode_procs 2 --output_dir {d}/d --output_mask_dir {d}/dm".format(d=tmp_path)).split())
     for n in names:
         ref = (tmp_path / "s" / n).read_bytes()
         assert (tmp_path / "p" / n).read_bytes() == ref and (tmp_path / "q" / n).read_bytes() == ref, n
-        assert (tmp_path / "r" / n).read_bytes() == ref, n
+        assert (tmp_path / "r" / n).read_bytes() == ref and (tmp_path / "d" / n).read_bytes() == ref, n
+        assert (tmp_path / "dm" / n).read_bytes() == (tmp_path / "sm" / n).read_bytes(), n
         assert (tmp_path / "pm" / n).read_bytes() == (tmp_path / "sm" / n).read_bytes(), n
         assert (tmp_path / "rm" / n).read_bytes() == (tmp_path / "sm" / n).read_bytes(), n
         assert np.array_equal(np.asarray(Image.open(tmp_path / "f" / n)), np.asarray(Image.open(tmp_path / "s" / n))), n
         assert np.array_equal(np.asarray(Image.open(tmp_path / "fm" / n)), np.asarray(Image.open(tmp_path / "sm" / n))), n
+    _run_test_py((base + "--decode_procs 1 --how_many 4 --output_dir {d}/hd".format(d=tmp_path)).split())
+    assert sorted(os.listdir(tmp_path / "hd")) == names[:6]
     _run_test_py((base + "--nThreads 1 --how_many 4 --output_dir {d}/h".format(d=tmp_path)).split())
     _run_test_py((base + "--nThreads 0 --serial_io --how_many 4 --output_dir {d}/hs".format(d=tmp_path)).split())
     assert sorted(os.listdir(tmp_path / "h")) == sorted(os.listdir(tmp_path / "hs")) == names[:6]       # test.py:21-22: whole batches

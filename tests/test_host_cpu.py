@@ -604,6 +604,19 @@ def test_png_writers_and_encoder_processes(tmp_path):
         bad = procs.submit(dict(job, first=0, paths=["x.png"], out_dir=str(tmp_path / "no_such_dir"), writer="pil"))
         with pytest.raises(RuntimeError):
             bad.result(timeout=60)
+        # decode jobs: pairs straight into slot 2 of the (writable) rings, as the dataset decodes them; a size mismatch is an error
+        Image.fromarray(np.asarray(ring[0, 3])).save(tmp_path / "in.png")
+        Image.fromarray(np.asarray(mring[0, 3])[::2, ::2].copy()).save(tmp_path / "in_m.png")          # half size: resized to the image
+        dj = dict(kind="decode", img_ring=str(tmp_path / "ring"), img_shape=ring.shape, sk_ring=str(tmp_path / "mring"), sk_shape=mring.shape,
+                  slot=2, first=1, image_paths=[str(tmp_path / "in.png")], mask_paths=[str(tmp_path / "in_m.png")])
+        assert procs.submit(dj).result(timeout=60) > 0
+        chk = np.memmap(str(tmp_path / "ring"), dtype=np.uint8, mode="r", shape=ring.shape)
+        assert np.array_equal(chk[2, 1], ring[0, 3])
+        want = np.asarray(Image.open(tmp_path / "in_m.png").convert("L").resize((48, 32)), dtype=np.uint8)
+        assert np.array_equal(np.memmap(str(tmp_path / "mring"), dtype=np.uint8, mode="r", shape=mring.shape)[2, 1], want)
+        Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(tmp_path / "small.png")
+        with pytest.raises(RuntimeError):
+            procs.submit(dict(dj, image_paths=[str(tmp_path / "small.png")])).result(timeout=60)
     finally:
         procs.close()
 
