@@ -187,6 +187,25 @@ def test_netM_and_netG_64_bf16_golden(eng, golden_dir):
         assert d.max() < TOL_NET and d.mean() < TOL_NET_MEAN
 
 
+def test_netG_taps_bf16_vs_oracle_bf16(eng):
+    """se_netG_forward_taps in bf16 mode (the tapped tensors leave through the bf16 layout converters): the style vector (fp32 in
+    both modes), the attention's input and the production attention's output against the oracle's bf16-mode taps."""
+    from oracle import sketchedit_oracle as O
+    img, sk = synth.make_inputs(2, 64, 64, seed=1234)
+    g_hard = (synth.uniform(3, "taps16.hard", (2, 1, 64, 64), 0, 1) < 0.5).astype(np.float32)
+    WG = synth.make_state_dict("G", 0)
+    taps = {}
+    with torch.no_grad():
+        O.netG_forward(WG, img, img, g_hard, g_hard, sk, taps=taps, act_dtype=BF)
+    ci, cs, ch = _cuda(img), _cuda(sk), _cuda(g_hard)
+    r = eng.netG_taps(ci, ci, ch, ch, cs, FLAGS)
+    assert set(r) >= {"pmconv6", "attn_out", "style_vec", "coarse", "fine"}
+    for k, scale in (("style_vec", 1.0), ("pmconv6", 1.0), ("attn_out", 1.0)):
+        want = taps[k]
+        d = np.abs(_np(r[k]) - _np(want))
+        assert d.max() < 4 * TOL_NET * max(1.0, float(want.abs().max())) and d.mean() < 4 * TOL_NET_MEAN * max(1.0, float(want.abs().mean())), k
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, True), (1, 128, 128, False), (1, 40, 72, True), (1, 256, 256, False)],
                          ids=["2x64-lowlat", "1x128", "1x40x72-lowlat", "1x256"])
 def test_inference_bf16_vs_oracle_bf16(eng, case):

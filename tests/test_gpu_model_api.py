@@ -303,6 +303,33 @@ def test_pipelined_test_py_writes_the_serial_loops_files(tmp_path):
     assert sorted(os.listdir(tmp_path / "h")) == sorted(os.listdir(tmp_path / "hs")) == names[:6]       # test.py:21-22: whole batches
 
 
+def test_pipeline_mixed_sizes_batch_one(tmp_path):
+    """test_places.sh's shape of work: --batchSize 1 over a list whose images have DIFFERENT sizes (512x512 and 408-wide scenes in
+    /root/reference/datasets/general_release/list.txt): the pipeline keeps one set of page-locked rings per size; files equal the
+    serial loop's byte for byte, through DataLoader workers and through the pipeline's own decoder / encoder processes."""
+    from PIL import Image
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    rng = np.random.RandomState(2)
+    sizes = [(64, 96), (40, 72), (64, 96), (48, 48), (40, 72)]
+    names = ["m%d.png" % i for i in range(len(sizes))]
+    for n, (h, w) in zip(names, sizes):
+        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(tmp_path / "images" / n)
+        Image.fromarray(((rng.rand(h, w) < 0.01) * 255).astype(np.uint8)).save(tmp_path / "edges" / n)
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    base = ("--batchSize 1 --name celeb --joint_train_inp --dataset_mode testimage --image_dirs {d}/images "
+            "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
+            "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --synthetic_weights ").format(d=tmp_path)
+    _run_test_py((base + "--nThreads 0 --serial_io --output_dir {d}/s".format(d=tmp_path)).split())
+    _run_test_py((base + "--nThreads 2 --encode_threads 2 --output_dir {d}/p".format(d=tmp_path)).split())
+    _run_test_py((base + "--decode_procs 2 --encode_procs 2 --output_dir {d}/d".format(d=tmp_path)).split())
+    for n, (h, w) in zip(names, sizes):
+        ref = (tmp_path / "s" / n).read_bytes()
+        assert np.asarray(Image.open(tmp_path / "s" / n)).shape == (h, w, 3)
+        assert (tmp_path / "p" / n).read_bytes() == ref and (tmp_path / "d" / n).read_bytes() == ref, n
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("se_ring_%d_" % os.getpid())]      # the rings are gone
+
+
 def test_celeb_sample_through_test_py_matches_the_reference(tmp_path, golden_dir, model):
     """BASELINE config 1: test_celeb.sh's command line (batch 1) on the reference's bundled face + sketch -- written
     back to PNG files from the fixture -- gives the PNGs the reference produces (fixture: tests/golden/make_golden.py)."""
