@@ -21,9 +21,11 @@ SOURCES = ["se_gconv.hip", "se_rconv16.hip", "se_rconv96.hip", "se_rtile.hip", "
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
 FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT, FLAG_BF16, FLAG_CONSERVATIVE = 32, 64, 128, 256, 512   # execution options (include/sketchedit_hip.h)
-# calls of at most this many pixels (four 256x256 images, one 512x512) run in the low-latency mode unless the caller says
-# otherwise: measured on MI355X, 4 x 256x256 3.59 ms vs 4.55 ms, 1 x 512x512 3.75 ms vs 5.09 ms (low-latency vs default)
-LOW_LATENCY_MAX_PIXELS = 4 * 256 * 256
+# calls of at most this many pixels (three 256x256 images) run in the low-latency mode unless the caller says otherwise.  Measured
+# on MI355X in round 6, low-latency vs default (the default mode now also overlaps netG's branches on two streams, which moved
+# the crossover down from four images): 256x256 B = 1 / 2 / 3 / 4: 1.20 / 1.75 / 2.47 / 3.05 ms vs 2.33 / 2.43 / 2.55 / 2.67;
+# 512x512 B = 1: 3.21 vs 2.94 (tools/ll_threshold.sh)
+LOW_LATENCY_MAX_PIXELS = 3 * 256 * 256
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
