@@ -21,11 +21,13 @@ SOURCES = ["se_gconv.hip", "se_rconv16.hip", "se_rconv96.hip", "se_rtile.hip", "
 SE_NET_G, SE_NET_M = 0, 1
 FLAG_USE_CAM, FLAG_POOL_MAX, FLAG_NO_MASK_CC, FLAG_NO_MASK_COARSE, FLAG_JOINT_TRAIN_INP = 1, 2, 4, 8, 16
 FLAG_LOW_LATENCY, FLAG_GRAPH, FLAG_PACKED_OUT, FLAG_BF16, FLAG_CONSERVATIVE = 32, 64, 128, 256, 512   # execution options (include/sketchedit_hip.h)
-# calls of at most this many pixels (three 256x256 images) run in the low-latency mode unless the caller says otherwise.  Measured
-# on MI355X in round 6, low-latency vs default (the default mode now also overlaps netG's branches on two streams, which moved
-# the crossover down from four images): 256x256 B = 1 / 2 / 3 / 4: 1.20 / 1.75 / 2.47 / 3.05 ms vs 2.33 / 2.43 / 2.55 / 2.67;
-# 512x512 B = 1: 3.21 vs 2.94 (tools/ll_threshold.sh)
+# Which calls run in the low-latency mode unless the caller says otherwise: at most three 256x256 images' worth of pixels, or ONE
+# image of up to 512x512.  Re-measured on MI355X in round 6 (tools/ll_threshold.sh), low-latency vs default, after the default
+# mode learned to overlap netG's branches and the low-latency mode to keep the Winograd kernels where ONE image's grid still
+# covers the chip: 256x256 B = 1 / 2 / 3 / 4: 1.20 / 1.75 / 2.45 / 3.05 ms vs 2.33 / 2.43 / 2.54 / 2.66; 384x384 B = 1: 2.02 vs
+# 2.59; 512x512 B = 1 / 2: 2.84 / 3.86 vs 2.96 / 3.80
 LOW_LATENCY_MAX_PIXELS = 3 * 256 * 256
+LOW_LATENCY_MAX_SINGLE_IMAGE = 512 * 512
 
 # every symbol declared in include/sketchedit_hip.h
 SYMBOLS = ["se_create", "se_destroy", "se_last_error", "se_version", "se_load_weights", "se_weights_ready",
@@ -363,7 +365,9 @@ class Engine:
     @staticmethod
     def is_low_latency(B, H, W, low_latency=None):
         """The low-latency mode is chosen by call size unless forced (True / False)."""
-        return B * H * W <= LOW_LATENCY_MAX_PIXELS if low_latency is None else bool(low_latency)
+        if low_latency is not None:
+            return bool(low_latency)
+        return B * H * W <= LOW_LATENCY_MAX_PIXELS or (B == 1 and H * W <= LOW_LATENCY_MAX_SINGLE_IMAGE)
 
     def exec_flags(self, B, H, W, low_latency=None, graph=False):
         """Execution-option bits for a call."""

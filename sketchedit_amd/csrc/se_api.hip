@@ -1202,7 +1202,18 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   // Low-latency mode (SE_FLAG_LOW_LATENCY, one or two images): the Winograd kernels' 64/128-tile workgroups would
   // occupy 16-32 of the 256 CUs, so every gated conv takes the direct kernel in its small-grid shape instead
   // (launch_gconv: 64-pixel tiles, rows split over blockIdx.y).  2.25x more multiply-adds on ~10x more CUs.
-  const bool use_wino = opt(OPT_WINOGRAD) != 0 && !c->low_latency;
+  // ... unless the layer's Winograd grid still covers enough of the chip (round 6; 0: never).  Measured (tools/ll_wino_sweep.sh):
+  // the 96 -> 192 kernels pay from 64 workgroups on (a third of the multiply-adds outweighs a quarter of the CUs: one 512x512
+  // image 3.22 -> 2.83 ms), the 96- and 48-row kernels only from 128 on (at 64 workgroups they cost one 256x256 image
+  // 1.20 -> 1.31 ms) -- SE_LL_WINO_MIN_WG / SE_LL_WINO48_MIN_WG.  The grid is counted PER IMAGE (the call's batch size does not
+  // enter): which kernel a layer runs must depend on the image size and the mode only, so that an image's result stays
+  // bit-identical across batch sizes, batch positions and ranks within the mode.
+  const int ll_min_wg = opt(OPT_LL_WINO_MIN_WG), ll_min_wg48 = opt(OPT_LL_WINO48_MIN_WG);
+  auto wino_grid_ok = [&](long wgs, bool n192 = false) {
+    const int m = n192 ? ll_min_wg : ll_min_wg48;
+    return !c->low_latency || (m > 0 && wgs >= m);
+  };
+  const bool use_wino = opt(OPT_WINOGRAD) != 0;
   const bool wino_src_ok = (!src1 && C0 == 96 && d.cin == 96) || (src1 && C0 == 96 && C1 == 96 && d.cin == 192);
   // the kernel addresses a source through 32-bit byte offsets (96 floats per pixel)
   const bool wino_addr_ok = (long long)B * Hin * Win * 384 < (1ll << 31);
@@ -1214,7 +1225,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
                       "using the direct kernel (about 2x slower) -- split the batch\n", d.name, B, Hin, Win);
     }
   }
-  if (use_wino && !d.up && L.d_u && wino_src_ok && wino_addr_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+  if (use_wino && !d.up && L.d_u && wino_src_ok && wino_addr_ok && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0 &&
+      wino_grid_ok(((long)(Hin / 2) * (Win / 2) + 63) / 64, true)) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.src1 = src1; wp.src1_vec = src1_vec;
@@ -1263,7 +1275,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   // 48 -> 192 (xconv5 of netG) on the hybrid kernel's 48-channel instantiation: 2 chunks per position, the second half empty
   {
     if (use_wino && opt(OPT_WINOGRAD_F43) != 0 && !d.up && !src1 && C0 == 48 && d.cin == 48 && d.cout == 192 && d.stride == 1 && L.d_u24 && L.d_ub24 &&
-        (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (4 * d.rate)) == 0) {
+        (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (4 * d.rate)) == 0 &&
+        wino_grid_ok(((long)(Hin / 2) * (Win / 4) + 31) / 32, true)) {
       WinoParams wp;
       memset(&wp, 0, sizeof wp);
       wp.src = src0; wp.upk = L.d_u24; wp.bias = L.d_ub24; wp.dst = dst;
@@ -1281,7 +1294,7 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   }
   const bool use_wino48 = opt(OPT_WINOGRAD48) != 0;
   if (use_wino && use_wino48 && !d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && (long long)B * Hin * Win * 192 < (1ll << 31) &&
-      (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+      (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0 && wino_grid_ok(((long)(Hin / 2) * (Win / 2) + 63) / 64)) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
@@ -1298,7 +1311,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   }
   // 24 -> 96 (xconv3 / pmconv3 of netG) on the same kernel, one chunk per position (se_wino48.hip CIN = 24): 16 of 36 products
   if (use_wino && use_wino48 && !d.up && L.d_u && L.d_ub && !src1 && C0 == 24 && d.cin == 24 && d.cout == 96 && d.stride == 1 &&
-      (long long)B * Hin * Win * 192 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0) {
+      (long long)B * Hin * Win * 192 < (1ll << 31) && (Hin % (2 * d.rate)) == 0 && (Win % (2 * d.rate)) == 0 &&
+      wino_grid_ok(((long)(Hin / 2) * (Win / 2) + 63) / 64)) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
@@ -1315,7 +1329,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   }
   const bool use_winoup = opt(OPT_WINOGRAD_UP) != 0;
   if (use_wino && use_winoup && d.up && L.d_u && L.d_ub && !src1 && C0 == 96 && d.cin == 96 &&
-      (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0) {
+      (long long)B * Hin * Win * 384 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0 &&
+      wino_grid_ok(4 * (((long)(Hin / 2) * (Win / 2) + 63) / 64))) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;
@@ -1334,7 +1349,8 @@ int run_gconv(se_ctx* c, const Layer& L, const float* src0, int C0, const float*
   // gen_deconv 48 -> 48: F(2x2,2x2) on the sub-pixel classes with the K pairing of the 48-channel kernels (se_wino_up48.hip)
   const bool use_winoup48 = opt(OPT_WINOGRAD_UP48) != 0;
   if (use_wino && use_winoup && use_winoup48 && d.up && L.d_u && L.d_ub && !src1 && C0 == 48 && d.cin == 48 && d.cout == 48 &&
-      (long long)B * Hin * Win * 192 < (1ll << 31) && (long long)B * Ho * Wo * 96 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0) {
+      (long long)B * Hin * Win * 192 < (1ll << 31) && (long long)B * Ho * Wo * 96 < (1ll << 31) && (Hin % 2) == 0 && (Win % 2) == 0 &&
+      wino_grid_ok(4 * (((long)(Hin / 2) * (Win / 2) + 63) / 64))) {
     WinoParams wp;
     memset(&wp, 0, sizeof wp);
     wp.src = src0; wp.upk = L.d_u; wp.bias = L.d_ub; wp.dst = dst;

@@ -52,7 +52,7 @@ hipError_t ensure_max_lds(const void* func, int bytes);
   X(WINOGRAD_F43, 1)     /* hybrid F(2,3)xF(4,3): 0 off, 1 everywhere, 2 netG only */ \
   X(WINO48_TILES, 64) X(WINOUP_TILES, 64)                                                                       \
   X(GCONV_FAST, 1) X(GCONV_VARIANT_N192, 0) X(GCONV_VARIANT_N96, 0) X(GCONV_VARIANT_N48, 0) X(GCONV_VARIANT_N24, 0) \
-  X(LL_STAGES, 2) X(FORK_DEFAULT, 1)                                                                                               \
+  X(LL_STAGES, 2) X(FORK_DEFAULT, 1) X(LL_WINO_MIN_WG, 64) X(LL_WINO48_MIN_WG, 128)                                                                                               \
   X(ATT_V1, 0) X(ATT_FUSED, -1) X(ATT_FUSED_BF16, -1) X(ATT_PTILDE_LDS, 1) X(ATT_STATS_LDS, 1) X(ATT_E16, 1)      \
   X(ATT_SYM, 1) X(ATT_PV_PT, -1)
 enum Opt {

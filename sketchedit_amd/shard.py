@@ -34,8 +34,8 @@ def global_mode(n, H, W):
     """The library's execution mode for a GLOBAL batch of n images: every rank runs its shard in the mode the unsharded
     call would run in, so an image's result does not depend on the world size (the library guarantees bit-identical
     results across batch positions and ranks only within one mode, include/sketchedit_hip.h)."""
-    from ._lib import LOW_LATENCY_MAX_PIXELS
-    return n * H * W <= LOW_LATENCY_MAX_PIXELS
+    from ._lib import Engine
+    return Engine.is_low_latency(n, H, W)
 
 
 def _accepts(forward, name):

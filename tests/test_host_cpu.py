@@ -367,10 +367,9 @@ def test_execution_mode_is_pinned_where_batch_composition_varies():
     shard.sharded_inference(fwd, torch.zeros(8, 3, 256, 256), torch.zeros(8, 1, 256, 256))
     shard.sharded_inference(fwd, torch.zeros(2, 3, 256, 256), torch.zeros(2, 1, 256, 256))
     assert seen == [False, True]
-    # (round 6: the crossover is three 256x256 images -- the default mode overlaps netG's branches too -- so four images and one
-    # 512x512 image run in the default mode)
-    assert shard.global_mode(8, 256, 256) is False and shard.global_mode(1, 512, 512) is False
-    assert shard.global_mode(3, 256, 256) is True and shard.global_mode(4, 256, 256) is False
+    # round 6: up to three 256x256 images' worth of pixels, or ONE image of up to 512x512 (tools/ll_threshold.sh)
+    assert shard.global_mode(8, 256, 256) is False and shard.global_mode(1, 512, 512) is True
+    assert shard.global_mode(3, 256, 256) is True and shard.global_mode(4, 256, 256) is False and shard.global_mode(2, 512, 512) is False
     # EditLine2Model: a call's own size picks the mode unless pinned (an interactive caller with --batchSize 8 that sends one
     # image keeps the low-latency kernels); test.py pins the mode of a FULL --batchSize batch for its whole file
     # list (batch_mode), so a ragged last batch does not change kernels
