@@ -22,11 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import sketchedit_oracle as O  # noqa: E402
 from sketchedit_amd import _lib, synth  # noqa: E402
+from sketchedit_amd.hostinfo import effective_cpus  # noqa: E402
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, effective_cpus()))
     res = {m: {"flips": 0, "pixels": 0, "max_abs": 0.0, "sum_abs": 0.0, "near": 0, "near_sum_abs": 0.0, "near_max_abs": 0.0} for m in (0, 1, 2)}
     per_set = {}
     for ws in sorted(synth.WEIGHT_SETS):
