@@ -15,8 +15,9 @@ class TestOptions(BaseOptions):
         parser.add_argument("--how_many", type=int, default=float("inf"), help="how many test images to run")
         # no reference counterpart: the I/O pipeline of test.py (sketchedit_amd/pipeline.py)
         parser.add_argument("--encode_threads", type=int, default=0, help="PNG encoder threads (0: as many as --nThreads, at least 1)")
-        parser.add_argument("--decode_procs", type=int, default=0, help="decode with this many worker PROCESSES straight into a shared page-locked ring instead of the "
-                            "DataLoader (0: --nThreads DataLoader workers); images of one batch must have one size")
+        parser.add_argument("--decode_procs", type=int, default=-1, help="decode with this many worker PROCESSES straight into a shared page-locked ring instead of "
+                            "DataLoader workers (-1: as many as --nThreads, i.e. --nThreads keeps its meaning 'decode workers'; 0: the DataLoader); "
+                            "images of one batch must have one size")
         parser.add_argument("--encode_procs", type=int, default=0, help="PNG encoder PROCESSES fed through a shared page-locked ring (0: threads); one process tops out near 2000 images/s")
         parser.add_argument("--png_writer", type=str, default="pil", choices=["pil", "fast"],
                             help="pil: PIL's defaults (adaptive filters, zlib 6; the files this repo has always written); fast: the reference's "

@@ -35,50 +35,76 @@ from .png_worker import save_png  # noqa: F401  (also test.py's serial loop)
 
 
 class _EncoderProcs:
-    """`n` codec processes (encoders; the same class runs the decoders of InferencePipeline.run_paths) (`python -m sketchedit_amd.png_worker`: numpy + PIL only, no torch, no HIP state -- plain child
+    """`n` codec processes (encoders; the same class runs the decoders of InferencePipeline.run_paths)
+    (`python -m sketchedit_amd.png_worker`: numpy + PIL only, no torch, no HIP state -- plain child
     processes, nothing forked from this one).  submit(job) -> Future of the seconds the job took; a job goes to the worker with
-    the fewest outstanding jobs; ONE reader thread collects the completion lines."""
+    the fewest outstanding jobs; ONE reader thread collects the completion lines from the workers' raw pipe descriptors (no
+    buffered reader in between: a buffered readline() can swallow a second line that the selector then never reports)."""
 
     def __init__(self, n):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
         self.ws = [subprocess.Popen([sys.executable, "-u", "-m", "sketchedit_amd.png_worker"], stdin=subprocess.PIPE,
-                                    stdout=subprocess.PIPE, env=env, cwd=root, text=True, bufsize=1) for _ in range(n)]
+                                    stdout=subprocess.PIPE, env=env, cwd=root, bufsize=0) for _ in range(n)]
         self.load = [0] * n
         self.futs = {}
         self.next_id = 0
         self.lock = threading.Lock()
-        for w in self.ws:                                   # "ready <pid>": imports done
-            if not w.stdout.readline().startswith("ready"):
-                raise RuntimeError("encoder process failed to start")
+        self.bufs = [bytearray() for _ in range(n)]
         self.sel = selectors.DefaultSelector()
         for k, w in enumerate(self.ws):
-            self.sel.register(w.stdout, selectors.EVENT_READ, k)
+            self.sel.register(w.stdout.fileno(), selectors.EVENT_READ, k)
+        ready, t_end = set(), time.perf_counter() + 120.0
+        while len(ready) < n:                               # "ready <pid>": imports done
+            if time.perf_counter() > t_end:
+                raise RuntimeError("PNG worker processes failed to start")
+            for key, _ in self.sel.select(timeout=1.0):
+                for line in self._lines(key.data):
+                    if line is None:
+                        raise RuntimeError("PNG worker process %d exited at start-up" % key.data)
+                    if line.startswith(b"ready"):
+                        ready.add(key.data)
         self.alive = True
         self.reader = threading.Thread(target=self._read, name="png-procs", daemon=True)
         self.reader.start()
 
+    def _lines(self, k):
+        """complete lines now available from worker k (raw read of its pipe); [None] at end of file"""
+        data = os.read(self.ws[k].stdout.fileno(), 65536)
+        if not data:
+            return [None]
+        buf = self.bufs[k]
+        buf += data
+        out = []
+        while True:
+            i = buf.find(b"\n")
+            if i < 0:
+                return out
+            out.append(bytes(buf[:i]))
+            del buf[:i + 1]
+
     def _read(self):
         while self.alive:
             for key, _ in self.sel.select(timeout=0.2):
-                line = key.fileobj.readline()
-                if not line:
-                    self.sel.unregister(key.fileobj)
+                k = key.data
+                for line in self._lines(k):
+                    if line is None:
+                        self.sel.unregister(key.fileobj)
+                        with self.lock:
+                            dead = [(i, f) for i, (f, kk) in self.futs.items() if kk == k]
+                            for i, _ in dead:
+                                del self.futs[i]
+                        for _, f in dead:
+                            f.set_exception(RuntimeError("PNG worker process %d died" % k))
+                        break
+                    kind, jid, rest = line.decode().split(" ", 2)
                     with self.lock:
-                        dead = [(i, f) for i, (f, k) in self.futs.items() if k == key.data]
-                        for i, _ in dead:
-                            del self.futs[i]
-                    for _, f in dead:
-                        f.set_exception(RuntimeError("encoder process %d died" % key.data))
-                    continue
-                kind, jid, rest = line.split(" ", 2)
-                with self.lock:
-                    f, k = self.futs.pop(int(jid))
-                    self.load[k] -= 1
-                if kind == "done":
-                    f.set_result(float(rest))
-                else:
-                    f.set_exception(RuntimeError("PNG encoder: " + json.loads(rest)))
+                        f, kk = self.futs.pop(int(jid))
+                        self.load[kk] -= 1
+                    if kind == "done":
+                        f.set_result(float(rest))
+                    else:
+                        f.set_exception(RuntimeError("PNG worker: " + json.loads(rest)))
 
     def submit(self, job):
         f = Future()
@@ -88,9 +114,7 @@ class _EncoderProcs:
             self.next_id += 1
             self.futs[jid] = (f, k)
             self.load[k] += 1
-        job = dict(job, id=jid)
-        self.ws[k].stdin.write(json.dumps(job) + "\n")
-        self.ws[k].stdin.flush()
+        self.ws[k].stdin.write((json.dumps(dict(job, id=jid)) + "\n").encode())
         return f
 
     def close(self):
@@ -100,9 +124,13 @@ class _EncoderProcs:
             except OSError:
                 pass
         for w in self.ws:
-            w.wait(timeout=60)
+            try:
+                w.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                w.kill()
         self.alive = False
         self.reader.join(timeout=5)
+        self.sel.close()
 
 
 class _Batch:

@@ -43,6 +43,8 @@ def main(argv=None):
         model.netM.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()})
     model.eval()
     mask_dir = getattr(opt, "output_mask_dir", None)
+    if opt.decode_procs < 0:
+        opt.decode_procs = max(0, int(opt.nThreads))      # --nThreads N = N decode workers: the pipeline's own, unless --decode_procs 0
     if not opt.serial_io:
         # every batch of the list, the ragged last one included, runs in the execution mode of a FULL --batchSize batch
         # (InferencePipeline pins model.batch_mode(H, W)): an image's PNG does not depend on where the file list ends

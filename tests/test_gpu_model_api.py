@@ -279,7 +279,7 @@ def test_pipelined_test_py_writes_the_serial_loops_files(tmp_path):
             "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
             "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --synthetic_weights ").format(d=tmp_path)
     _run_test_py((base + "--nThreads 0 --serial_io --output_dir {d}/s --output_mask_dir {d}/sm".format(d=tmp_path)).split())
-    _run_test_py((base + "--nThreads 2 --encode_threads 3 --pipeline_depth 2 --output_dir {d}/p --output_mask_dir {d}/pm".format(d=tmp_path)).split())
+    _run_test_py((base + "--nThreads 2 --decode_procs 0 --encode_threads 3 --pipeline_depth 2 --output_dir {d}/p --output_mask_dir {d}/pm".format(d=tmp_path)).split())      # DataLoader workers
     _run_test_py((base + "--nThreads 0 --pipeline_depth 1 --output_dir {d}/q".format(d=tmp_path)).split())
     # encoder PROCESSES fed through the shared page-locked ring (hipHostRegister on a /dev/shm file), masks too
     _run_test_py((base + "--nThreads 2 --encode_procs 2 --output_dir {d}/r --output_mask_dir {d}/rm".format(d=tmp_path)).split())
@@ -321,7 +321,7 @@ def test_pipeline_mixed_sizes_batch_one(tmp_path):
             "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
             "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --synthetic_weights ").format(d=tmp_path)
     _run_test_py((base + "--nThreads 0 --serial_io --output_dir {d}/s".format(d=tmp_path)).split())
-    _run_test_py((base + "--nThreads 2 --encode_threads 2 --output_dir {d}/p".format(d=tmp_path)).split())
+    _run_test_py((base + "--nThreads 2 --decode_procs 0 --encode_threads 2 --output_dir {d}/p".format(d=tmp_path)).split())
     _run_test_py((base + "--decode_procs 2 --encode_procs 2 --output_dir {d}/d".format(d=tmp_path)).split())
     for n, (h, w) in zip(names, sizes):
         ref = (tmp_path / "s" / n).read_bytes()

@@ -623,6 +623,25 @@ def test_png_writers_and_encoder_processes(tmp_path):
         procs.close()
 
 
+def test_worker_pool_reader_loses_no_completion_line(tmp_path):
+    """Thousands of tiny jobs on a few workers: completion lines arrive back to back in one pipe read.  A buffered readline()
+    behind a selector swallowed the second line of such a read and the caller waited for ever (found in round 6 as a hang of
+    the GPU suite); the reader now splits raw pipe reads itself."""
+    from sketchedit_amd.pipeline import _EncoderProcs
+    ring = np.memmap(str(tmp_path / "ring"), dtype=np.uint8, mode="w+", shape=(1, 4, 8, 8, 3))
+    ring[:] = 7
+    ring.flush()
+    os.makedirs(tmp_path / "o")
+    procs = _EncoderProcs(3)
+    try:
+        job = dict(rgb_ring=str(tmp_path / "ring"), rgb_shape=ring.shape, mask_ring=None, mask_shape=None, slot=0, out_dir=str(tmp_path / "o"),
+                   mask_dir=None, writer="fast")
+        futs = [procs.submit(dict(job, first=i % 4, paths=["x%d.png" % (i % 50)])) for i in range(2000)]
+        assert all(f.result(timeout=120) >= 0 for f in futs)
+    finally:
+        procs.close()
+
+
 def test_effective_cpus_honours_a_cgroup_quota(monkeypatch, tmp_path):
     from sketchedit_amd import hostinfo
     n = hostinfo.effective_cpus()
