@@ -112,3 +112,22 @@ def test_bench_eight_ranks_propagate_a_late_rank_failure():
     env["SE_BENCH_FAIL_RANK"] = "7"
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
     assert r.returncode != 0 and not r.stdout.strip()
+
+
+@pytest.mark.timeout(600)
+def test_bench_e2e_leg_files_to_files():
+    """`bench.py --e2e` (the child the default invocation runs for `secondary[2]`): PNG files in, PNG files out through the
+    pipelined test.py loop, both writers, every file written, stage rates and the host-codec yardstick on the line; also through
+    DataLoader workers.  Small: 48 list entries over 12 unique 64x64 pairs."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--size", "64", "--batch", "8", "--e2e-images", "48", "--e2e-unique", "12",
+            "--e2e-cap-seconds", "0.4", "--e2e-workers", "2", "--e2e-encoders", "2"]
+    for extra in ([], ["--e2e-dataloader"], ["--e2e-encode-threads"]):
+        r = subprocess.run(base + extra, cwd=ROOT, capture_output=True, text=True, timeout=500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = _one_json_line(r.stdout)
+        assert d["metric"] == "e2e_images_per_sec" and d["value"] > 0 and d["host"]["cpus_effective"] >= 1
+        assert set(d["writers"]) == {"pil", "fast"}
+        for w in d["writers"].values():
+            assert w["images"] == 48 and w["files_written"] == 48 and w["e2e_images_per_sec"] > 0
+            assert set(w["stage_images_per_sec"]) == {"decode", "h2d", "forward", "d2h", "encode"}
+            assert w["bottleneck"] in w["stage_images_per_sec"] and w["host_codec"]["both_ips"] > 0
