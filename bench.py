@@ -577,8 +577,10 @@ def e2e_leg(args):
             pipe = InferencePipeline(model, opt.output_dir, None, encode_threads=e, depth=args.e2e_depth, timing=True, verbose=False,
                                      encode_procs=0 if args.e2e_encode_threads else e, max_pending_batches=args.e2e_pending, png_writer=writer,
                                      decode_procs=0 if args.e2e_dataloader else w)
-            st = dict(pipe.run(loader, float("inf"), B) if args.e2e_dataloader else pipe.run_paths(loader.dataset, float("inf"), B))
-            pipe.close()
+            try:
+                st = dict(pipe.run(loader, float("inf"), B) if args.e2e_dataloader else pipe.run_paths(loader.dataset, float("inf"), B))
+            finally:
+                pipe.close()
             thr1 = cgroup_throttle_stats()
             img = st["images"]
             # the encoders' rate on what the network really wrote (procedural weights paint the hole with texture that

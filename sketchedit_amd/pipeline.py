@@ -25,6 +25,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
+import atexit
 import json
 import selectors
 import subprocess
@@ -137,6 +138,20 @@ class _Batch:
     __slots__ = ("paths", "n", "slot_in", "slot_out", "dev", "ev0", "ev_h2d", "ev_fwd0", "ev_fwd", "ev_d2h", "futs", "shape", "rings", "dfuts")
 
 
+_ring_files = set()      # shared rings of this process still on /dev/shm (removed by close(); by the exit hook if a caller never got there)
+
+
+def _unlink_leftover_rings():
+    for path in list(_ring_files):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+atexit.register(_unlink_leftover_rings)
+
+
 class _PinnedRing:
     """`n` slots of one uint8 array shape in page-locked host memory, allocated ONCE (a pinned allocation maps memory into the
     GPU's address space -- not something to do per batch).  With `shared` the ring is a file on /dev/shm registered with the
@@ -150,6 +165,7 @@ class _PinnedRing:
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
             fd, self.path = tempfile.mkstemp(prefix="se_ring_%d_" % os.getpid(), dir=base)
             os.close(fd)
+            _ring_files.add(self.path)
             self.mm = np.memmap(self.path, dtype=np.uint8, mode="w+", shape=(n,) + self.shape)
             self.t = torch.from_numpy(self.mm)
             rc = torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), nbytes, 0)
@@ -170,6 +186,7 @@ class _PinnedRing:
                 os.unlink(self.path)
             except OSError:
                 pass
+            _ring_files.discard(self.path)
             self.path = None
 
 
@@ -417,6 +434,13 @@ class InferencePipeline:
         self.stats["encode_drain_s"] = time.perf_counter() - t0
         self.stats["wall_s"] = time.perf_counter() - t_start
         return self.stats
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def close(self):
         if self.dprocs is not None:
