@@ -21,6 +21,9 @@ class EditLine2Model(torch.nn.Module):
         networks.modify_commandline_options(parser, is_train)
         # no reference counterpart: SE_FLAG_CONSERVATIVE of the C-ABI (include/sketchedit_hip.h, INTEGRATION.md "Precision
         # choice") -- the mask predictor on the F(2x2,3x3) Winograd form; for checkpoints whose mask logits sit at 0.5
+        parser.add_argument("--precision", type=str, default="f32", choices=["f32", "bf16"],
+                            help="f32: the reference's arithmetic (1e-3 parity bound); bf16: SE_FLAG_BF16 -- bf16 storage and MFMA, fp32 accumulate "
+                                 "(BASELINE config 5; compared against the oracle's bf16 mode, not the 1e-3 bound)")
         parser.add_argument("--conservative_mask", action="store_true",
                             help="netM on the conservative Winograd form (fewer hard-mask flips vs the fp32 CPU reference, +1.7 %% time)")
         return parser
@@ -57,6 +60,7 @@ class EditLine2Model(torch.nn.Module):
         if self._engine is None:
             self._engine = _lib.Engine(self.opt.gpu_ids[0])
             self._engine.set_conservative(getattr(self.opt, "conservative_mask", False))
+            self._engine.set_precision(getattr(self.opt, "precision", "f32") or "f32")
             self.netG.bind_engine(self._engine)
             self.netM.bind_engine(self._engine)
         self.netG.engine()                                # (re)upload weights if they changed

@@ -303,6 +303,52 @@ def test_pipelined_test_py_writes_the_serial_loops_files(tmp_path):
     assert sorted(os.listdir(tmp_path / "h")) == sorted(os.listdir(tmp_path / "hs")) == names[:6]       # test.py:21-22: whole batches
 
 
+def test_precision_option_reaches_the_bf16_path(tmp_path, model):
+    """--precision bf16 (no reference counterpart; BASELINE config 5) through the reference's entry points: the model built from
+    the option runs the library's bf16 mode (bit-identical to Engine.set_precision('bf16')), and test.py --precision bf16 writes
+    PNGs within bf16 noise of the fp32 run's."""
+    from PIL import Image
+    from sketchedit_amd import models
+    from sketchedit_amd._lib import Engine
+    from sketchedit_amd.options.test_options import TestOptions
+    for sub in ("images", "edges"):
+        os.makedirs(tmp_path / sub)
+    rng = np.random.RandomState(4)
+    names = ["b%d.png" % i for i in range(3)]
+    for n in names:
+        Image.fromarray(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8)).save(tmp_path / "images" / n)
+        Image.fromarray(((rng.rand(64, 64) < 0.01) * 255).astype(np.uint8)).save(tmp_path / "edges" / n)
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    base = ("--batchSize 2 --nThreads 0 --name celeb --joint_train_inp --dataset_mode testimage --image_dirs {d}/images "
+            "--mask_dirs {d}/edges --image_lists {d}/list.txt --image_postfix .png --mask_postfix .png --model editline2 "
+            "--netG deepfillc2 --pool_type max --use_cam --which_epoch latest --synthetic_weights ").format(d=tmp_path)
+    _run_test_py((base + "--output_dir {d}/f".format(d=tmp_path)).split())
+    _run_test_py((base + "--precision bf16 --output_dir {d}/h".format(d=tmp_path)).split())
+    diffs = []
+    for n in names:
+        a, b = np.asarray(Image.open(tmp_path / "f" / n)).astype(int), np.asarray(Image.open(tmp_path / "h" / n)).astype(int)
+        diffs.append(np.abs(a - b))
+    d = np.concatenate([x.ravel() for x in diffs])
+    assert d.max() > 0 and np.mean(d) < 2.0 and np.mean(d > 16) < 0.02            # another arithmetic, the same picture
+    # the option against the engine-level switch, bit for bit
+    opt = TestOptions().parse((base + "--precision bf16 --output_dir {d}/x".format(d=tmp_path)).replace("--synthetic_weights ", "").split(), quiet=True)
+    opt.isSkip = True
+    m = models.create_model(opt)
+    m.netG.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("G", 0).items()})
+    m.netM.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("M", 0).items()})
+    m.eval()
+    img, sk = synth.make_inputs(2, 64, 64, seed=7)
+    with torch.no_grad():
+        comp, mask = m({"image": torch.from_numpy(img), "mask": torch.from_numpy(sk)}, mode="inference")
+    e = Engine(0)
+    e.load_state_dict("M", synth.make_state_dict("M", 0))
+    e.load_state_dict("G", synth.make_state_dict("G", 0))
+    e.set_precision("bf16")
+    r = e.inference(torch.from_numpy(img).cuda(), torch.from_numpy(sk).cuda(), 1 | 2 | 16)
+    assert torch.equal(comp, r["composed"]) and torch.equal(mask, r["mask"])
+    e.close()
+
+
 def test_pipeline_mixed_sizes_batch_one(tmp_path):
     """test_places.sh's shape of work: --batchSize 1 over a list whose images have DIFFERENT sizes (512x512 and 408-wide scenes in
     /root/reference/datasets/general_release/list.txt): the pipeline keeps one set of page-locked rings per size; files equal the
