@@ -158,6 +158,7 @@ struct se_ctx {
   int cur_net = SE_NET_G;   // network whose plan is running (plan_netM / plan_netG; per-op entry points: G)
   bool bf16 = false;        // SE_FLAG_BF16 of the running call: bf16 activations / weights, fp32 accumulate
   bool serial = false;             // default mode on one stream (set while the profiler is on: per-kernel durations)
+  bool fork2 = true;               // SE_FORK_DEFAULT, snapshot taken where a call enters the library
   bool conservative = false;       // SE_FLAG_CONSERVATIVE of the running call: netM's 96 -> 192 layers on F(2x2,3x3)
   const se_netG_taps* taps = nullptr;      // se_netG_forward_taps: intermediate outputs of the running netG plan
   float* vbias_ws = nullptr;       // [B][9][192] scratch for the folded vector source of the next two-source layer (plan_netG)
@@ -1449,7 +1450,9 @@ struct Plan {
   // Default mode (round 6): the same two-stream plan (SE_FORK_DEFAULT=0: one stream) -- the tail of one branch's kernel runs
   // under the head of the other's: +2 % on configs 2, 3 and 5.  While the in-library profiler is on, the default mode is
   // planned on ONE stream (c->serial): an event pair around a launch measures that kernel only when nothing else shares the chip.
-  bool forked() const { return (c->low_latency || (opt(OPT_FORK_DEFAULT) != 0 && !c->serial)) && c->st_side; }
+  // (c->fork2 = SE_FORK_DEFAULT as it was when the call entered the library: one snapshot per call, so a switch flipped by
+  // another thread cannot leave a plan with a fork and no join)
+  bool forked() const { return (c->low_latency || (c->fork2 && !c->serial)) && c->st_side; }
   int side_begin() {
     if (!forked()) return 0;
     ar = &c->arena2;
@@ -1994,6 +1997,7 @@ size_t se_workspace_bytes(se_ctx* c, int B, int H, int W) {
   if (!c) return 0;
   std::lock_guard<std::mutex> lk(c->mu);
   if (check_dims(c, B, H, W)) return 0;
+  c->fork2 = opt(OPT_FORK_DEFAULT) != 0;
   // every flag combination that changes the allocation sequence (a first-fit arena does not peak monotonically):
   // attention on/off, 4- or 8-channel style input, in-line or concurrent branches, fp32 or bf16 activations
   size_t peak = 0;
@@ -2031,6 +2035,7 @@ int se_netM_forward_ex(se_ctx* c, void* stream, const float* image, const float*
   if (!image || !sketch || !mask_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
   c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
+  c->fork2 = opt(OPT_FORK_DEFAULT) != 0;
   exec_flags &= SE_FLAG_LOW_LATENCY | SE_FLAG_BF16 | SE_FLAG_CONSERVATIVE;
   const int nb = pass_size(c, B, H, W, exec_flags);
   if (!nb) return 1;
@@ -2060,6 +2065,7 @@ int se_netG_forward_taps(se_ctx* c, void* stream, const float* x, const float* x
   if (!x || !x2 || !mask || !mask2 || !guide || !fine_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
   c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
+  c->fork2 = opt(OPT_FORK_DEFAULT) != 0;
   const int nb = pass_size(c, B, H, W, flags);
   if (!nb) return 1;
   if (taps && nb < B) return fail(c, "se_netG_forward_taps: %d images do not fit one pass (%d)", B, nb);
@@ -2127,6 +2133,7 @@ int se_inference(se_ctx* c, void* stream, const float* image, const float* sketc
   if (!image || !sketch || !composed_out || (!mask_out && !(flags & SE_FLAG_PACKED_OUT)) || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
   c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
+  c->fork2 = opt(OPT_FORK_DEFAULT) != 0;
   if (!(flags & SE_FLAG_GRAPH) || c->prof.on)
     return enqueue_inference(c, stream, image, sketch, composed_out, mask_out, hard_out, maskim_out, coarse_out, fine_out, ws,
                              ws_bytes, B, H, W, flags);
@@ -2212,6 +2219,7 @@ int se_inference_u8(se_ctx* c, void* stream, const float* image, const float* sk
   if (!image || !sketch || !rgb_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
   c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
+  c->fork2 = opt(OPT_FORK_DEFAULT) != 0;
   return inference_u8_locked(c, stream, image, sketch, rgb_out, mask_u8_out, ws, ws_bytes, B, H, W, flags, 0);
 }
 
@@ -2238,6 +2246,7 @@ int se_inference_u8io(se_ctx* c, void* stream, const unsigned char* image_u8, co
   if (!image_u8 || !sketch_u8 || !rgb_out || !ws) return fail(c, "null pointer argument");
   HIPCHK(c, hipSetDevice(c->device));
   c->serial = c->prof.on;      // profiler on: default mode planned on one stream (Plan::forked)
+  c->fork2 = opt(OPT_FORK_DEFAULT) != 0;
   const size_t plane = ((size_t)B * H * W * 4 + 255) & ~(size_t)255;
   if (ws_bytes < 6 * plane) return fail(c, "workspace too small: %zu bytes", ws_bytes);
   float* image = (float*)((char*)ws + ws_bytes - 4 * plane);      // (B,3,H,W) contiguous: 3 B H W floats <= 3 planes
