@@ -163,9 +163,18 @@ class _PinnedRing:
         nbytes = int(np.prod((n,) + self.shape))
         if shared:
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            try:                                     # a container's /dev/shm may be 64 MB: fall back to the temp directory
+                st = os.statvfs(base)
+                if st.f_bavail * st.f_frsize < nbytes + (64 << 20):
+                    base = tempfile.gettempdir()
+            except OSError:
+                pass
             fd, self.path = tempfile.mkstemp(prefix="se_ring_%d_" % os.getpid(), dir=base)
-            os.close(fd)
             _ring_files.add(self.path)
+            try:
+                os.posix_fallocate(fd, 0, nbytes)    # reserve the pages now: ENOSPC here instead of a SIGBUS at the first touch
+            finally:
+                os.close(fd)
             self.mm = np.memmap(self.path, dtype=np.uint8, mode="w+", shape=(n,) + self.shape)
             self.t = torch.from_numpy(self.mm)
             rc = torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), nbytes, 0)
